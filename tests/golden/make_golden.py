@@ -1,0 +1,73 @@
+"""Generates the committed golden vectors from the CPU oracle (run AFTER tests/test_oracle_kat.py passes).
+
+The reference itself cannot be imported in the build container (tensorflow / tfp / gpflow absent),
+so these vectors come from the oracle, which is pinned by the reference's stored notebook outputs
+(KAT-1 / KAT-2) and by the cross-identities in tests/test_oracle_identities.py.
+
+    python tests/golden/make_golden.py
+
+Inputs are regenerated from seeds (lcgp_amd/synth.py, tests/kat_data.py); only expected outputs are
+stored: NLL, gradient w.r.t. the unconstrained vector, per-component pieces, and a few predictions.
+"""
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+
+from oracle import lcgp_oracle as orc  # noqa: E402
+from lcgp_amd import synth  # noqa: E402
+from tests import kat_data  # noqa: E402
+
+
+def case_models():
+    xtr, ytr, xte, _ = kat_data.kat_dataset()
+    yield 'kat_rep', 1, orc.OracleLCGP(y=ytr, x=xtr, q=3, diag_error_structure=[1, 1, 1], submethod='rep'), xte[::40]
+    x, y = synth.make_full(64, 64, 2, 4, 3)
+    yield 'full_n64', 64, orc.OracleLCGP(y=y, x=x, q=3, submethod='full'), \
+        np.random.default_rng(640).uniform(0, 1, (7, 2))
+    x, y = synth.make_full(65, 150, 3, 5, 2)
+    yield 'full_n150_grouped', 65, orc.OracleLCGP(y=y, x=x, q=2, submethod='full', diag_error_structure=[2, 3],
+                                                   robust_mean=False), \
+        np.random.default_rng(650).uniform(0, 1, (5, 3))
+    x, y = synth.make_rep(66, 70, 3, 2, 4, 4)
+    yield 'rep_n70', 66, orc.OracleLCGP(y=y, x=x, submethod='rep'), np.random.default_rng(660).uniform(0, 1, (6, 2))
+    x, y = synth.make_rep(67, 33, 4, 1, 3, 3)
+    yield 'rep_n33_raw', 67, orc.OracleLCGP(y=y, x=x, submethod='rep', rep_standardize_ybar=False), \
+        np.random.default_rng(670).uniform(0, 1, (6, 1))
+    x, y, cfg = synth.make_config(2)
+    yield 'cfg2_n1024', 2, orc.OracleLCGP(y=y, x=x, q=cfg['q'], submethod='full'), None
+
+
+def main():
+    out = {}
+    for name, c, m, x0 in case_models():
+        pts = synth.param_points(c, m.get_unconstrained())
+        vals, grads = [], []
+        for u in pts:
+            v, g = m.loss_and_grad_unconstrained(u)
+            vals.append(v)
+            grads.append(g)
+        out[name + '/u'] = np.stack(pts)
+        out[name + '/nll'] = np.array(vals)
+        out[name + '/grad'] = np.stack(grads)
+        out[name + '/diag_D'] = np.asarray(m.diag_D)
+        if x0 is not None:
+            m.set_unconstrained(pts[1])
+            pred = m.predict(x0, return_fullcov=(m.submethod == 'full'))
+            out[name + '/x0'] = x0
+            out[name + '/ypred'] = pred[0]
+            out[name + '/ypredvar'] = pred[1]
+            out[name + '/yconfvar'] = pred[2]
+            if m.submethod == 'full':
+                out[name + '/fullcov'] = pred[3]
+        print(name, 'n=%d q=%d' % (m.n, m.q), 'nll', vals)
+    np.savez_compressed(os.path.join(HERE, 'lcgp_golden.npz'), **out)
+    print('wrote', os.path.join(HERE, 'lcgp_golden.npz'))
+
+
+if __name__ == '__main__':
+    main()
