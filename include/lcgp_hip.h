@@ -1,0 +1,113 @@
+/* lcgp_hip.h -- C ABI of liblcgp_hip.so: the MI355X (gfx950) hot path of LCGP.
+ *
+ * The reference (mosesyhc/LCGP) is pure Python on TensorFlow; it has no FFI.  The "interface" each
+ * entry point below replaces is therefore a span of reference Python (file:line cited per function).
+ * The Python host side (lcgp_amd/lcgp.py) binds these with ctypes; INTEGRATION.md shows the stub a
+ * reference maintainer would add.
+ *
+ * Conventions
+ *  - every pointer is a DEVICE pointer on the current device unless marked "host";
+ *  - matrices are row-major;  `dtype`: 0 = float64, 1 = float32 (the reference is float64 only);
+ *  - `stream` is a hipStream_t passed as void* (NULL = the null stream); every call only ENQUEUES
+ *    work on that stream and returns; nothing is allocated, freed or synchronised inside;
+ *  - the caller owns all memory, including `workspace` (size from lcgp_workspace_bytes);
+ *  - return value 0 = enqueued; < 0 = bad argument / HIP error (see lcgp_last_error()).
+ *    A non positive-definite matrix is reported through the `info` word of the output block,
+ *    not through the return value (the call is asynchronous).
+ *
+ * theta block (host computes it, one H2D copy per evaluation), per local component k, doubles:
+ *     [ ell_0 .. ell_{d-1} | scale | nug | D_k | psi_0 .. psi_{p-1} ]        width d + 3 + p
+ *   ell/scale/nug are the CONSTRAINED values (what the reference calls lLmb[k], lLmb0[k],
+ *   lnugGPs[k]; lcgp.py:515-532), D_k = diag_D[k] (lcgp.py:480), psi = phi[:,k]/sigma
+ *   (lcgp.py:646) -- for the replicated path sigma is sigma_used (lcgp.py:576-584).
+ *
+ * output block, per local component k, doubles:
+ *     [ half_logdet | quad | info | g_ell_0 .. g_ell_{d-1} | g_scale | g_nug | gsig_0 .. gsig_{p-1} ]
+ *                                                                         width d + 5 + p
+ *   half_logdet = sum_i log L_ii            (= 1/2 log det A_k, A_k = I + D_k (C_k o s s^T))
+ *   quad        = b^T (b - A_k^-1 b)        (so NLL_k = half_logdet - quad / (2 D_k))
+ *   info        = 0, or 1 + index of the first non-positive pivot
+ *   g_*         = d NLL_k / d (constrained ell, scale, nug)
+ *   gsig_a      = sum_i Y[a,i] (b_i - z_i)  (host turns it into d NLL / d lsigma2s)
+ */
+#ifndef LCGP_HIP_H
+#define LCGP_HIP_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LCGP_F64 0
+#define LCGP_F32 1
+
+/* library version (major*10000 + minor*100 + patch) and last error text (host string). */
+int lcgp_version(void);
+const char* lcgp_last_error(void);
+
+/* width of the theta / output blocks described above. */
+int lcgp_theta_width(int d, int p);
+int lcgp_out_width(int d, int p);
+
+/* bytes of `workspace` needed by lcgp_nll_grad / lcgp_potrf_logdet / lcgp_potri for q_local components. */
+int lcgp_workspace_bytes(int dtype, int n, int d, int p, int q_local, size_t* bytes /*host out*/);
+
+/* Matern32(x1, x2, llmb, llmb0, lnug)  -- covmat.py:5-55 (build branch 31-55).
+ * out (n1 x n2, row-major).  `same` != 0 adds the nugget term on the diagonal (the reference adds it
+ * iff x1 and x2 have equal shape and bitwise-equal values, covmat.py:46-51; the caller decides). */
+int lcgp_matern32(void* stream, int dtype, int n1, int n2, int d,
+                  const void* x1, const void* x2,
+                  const double* ell /*host, d*/, double scale, double nug, int same, void* out);
+
+/* K1: A_k = I + D_k * (C_k o sr sr^T) for all local components, into the workspace
+ * (lcgp.py:651 for the full path; lcgp.py:606 + 616 for the replicated path, sr = sqrt(r)).
+ * Only the lower-triangular 64x64 tiles are written.  sr may be NULL (all ones). */
+int lcgp_kernel_build(void* stream, int dtype, int n, int d, int p, int q_local,
+                      const void* x /*n x d*/, const void* sr /*n or NULL*/,
+                      const double* theta, void* workspace);
+
+/* K2: blocked Cholesky A_k = L_k L_k^T of the matrices left by lcgp_kernel_build, in place, plus
+ * W = L^-1 blocks needed later.  Replaces tf.linalg.eigh (lcgp.py:652) / tf.linalg.cholesky
+ * (lcgp.py:617) and the log-determinant (lcgp.py:660 / 624).
+ * half_logdet (q_local doubles) and info (q_local ints) are written on the device. */
+int lcgp_potrf_logdet(void* stream, int dtype, int n, int d, int p, int q_local, void* workspace,
+                      double* half_logdet, int* info);
+
+/* K4: A_k^-1 (lower tiles) from the factor left by lcgp_potrf_logdet.  Replaces the dense
+ * U diag(.) U^T products of lcgp.py:654 / 705-715 and cholesky_solve with identity (lcgp.py:785). */
+int lcgp_potri(void* stream, int dtype, int n, int d, int p, int q_local, void* workspace);
+
+/* copies matrix `which` (0 = A/L, 1 = L^-1, 2 = A^-1) of local component k out of the workspace as a
+ * dense n x n row-major matrix (lower triangle valid, upper triangle mirrored); for tests. */
+int lcgp_fetch_matrix(void* stream, int dtype, int n, int d, int p, int q_local, const void* workspace,
+                      int which, int k, void* out /*n x n*/);
+
+/* The whole hot path for q_local components: build + Cholesky + inverse + z = A^-1 b + fused gradient
+ * contraction.  Replaces one call of LCGP.neglpost (lcgp.py:635-666) or LCGP.neglpost_rep
+ * (lcgp.py:554-630) TOGETHER WITH the tf.GradientTape backward pass gpflow runs around it
+ * (lcgp.py:538-539), for the components held by this rank.
+ *   x  : n x d standardised inputs (x_unique_s for the replicated path)
+ *   Y  : p x n outputs the latent targets are projected from (standardised y; sqrt(r) o ybar for rep)
+ *   sr : NULL for the full path; sqrt(r) (n) for the replicated path
+ *   theta, out : device blocks described at the top (q_local rows each) */
+int lcgp_nll_grad(void* stream, int dtype, int n, int d, int p, int q_local,
+                  const void* x, const void* Y, const void* sr,
+                  const double* theta, void* workspace, double* out);
+
+/* K6 prediction (lcgp.py:808-859 / 864-930 with the caches of 685-803): for local component k and
+ * n0 new inputs x0 (already standardised) computes
+ *     ghat[k, :] = c0k (sr o z_k)                       (lcgp.py:831 / 888)
+ *     gvar[k, :] = scale_k - D_k rowsum((c0k o sr) A_k^-1 (c0k o sr)^T)   (lcgp.py:832 / 891-894)
+ * using A_k^-1 and z_k left in the workspace by the last lcgp_nll_grad call with the same theta.
+ * `same` as in lcgp_matern32 (nugget on the diagonal when x0 is the training set itself).
+ * scratch: 2 * n0pad * npad elements of dtype (n0pad, npad = n0, n rounded up to 64). */
+int lcgp_predict(void* stream, int dtype, int n, int d, int p, int q_local,
+                 const void* x, const void* sr, const double* theta, const void* workspace,
+                 int n0, const void* x0, int same, void* scratch,
+                 double* ghat /*q_local x n0*/, double* gvar /*q_local x n0*/);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LCGP_HIP_H */

@@ -1,0 +1,996 @@
+// lcgp_hip.hip -- gfx950 (MI355X) kernels + C ABI for the LCGP fit/predict hot path.
+//
+// What the reference does per L-BFGS-B evaluation (lcgp.py:635-666 / 554-630 + the gpflow tape):
+// for each latent component k build C_k (covmat.py:31-55), decompose it, reduce to a scalar, and
+// back-propagate.  Here, per component:  A = I + D (C o s s^T)  ->  A = L L^T (blocked Cholesky,
+// 64x64 diagonal blocks in LDS, fp64 MFMA trailing updates)  ->  W = L^-1 (level-parallel TRMMs)
+// ->  A^-1 = W^T W (one MFMA launch)  ->  z = A^-1 b  ->  fused contraction of
+// G = s s^T o (D/2 A^-1 - z z^T/2) with dC/dtheta recomputed on the fly from x.
+// All components of the rank are batched in every launch (blockIdx.y = component).
+//
+// Layout in HBM: per component three npad x npad row-major matrices (npad = n rounded up to 64,
+// the padding is the identity so every kernel works on whole 64x64 tiles):
+//   M : A, then L (lower tiles)      W : L^-1 (lower tiles)      V : scratch, then A^-1 (lower tiles)
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+#include <math.h>
+
+#include "../../include/lcgp_hip.h"
+
+#define LCGP_VERSION 100
+
+namespace {
+
+constexpr int TS = 64;    // tile size (rows/cols of one tile)
+constexpr int KT = 16;    // k extent of one LDS stage
+constexpr int LDM = 80;   // LDS leading dimension of a [k][m] stage: 80 = 16 (mod 32) -> the two k rows a
+                          // 32-lane group reads land on disjoint banks (ds_read_b64 / ds_read_b32)
+constexpr int DMAX = 16;  // max input dimension handled by the fused kernels
+
+typedef double d4 __attribute__((ext_vector_type(4)));
+typedef float f4 __attribute__((ext_vector_type(4)));
+
+thread_local char g_err[256] = "";
+
+inline int fail(const char* what, hipError_t e) {
+    snprintf(g_err, sizeof(g_err), "%s: %s", what, hipGetErrorString(e));
+    return -2;
+}
+inline int bad(const char* what) {
+    snprintf(g_err, sizeof(g_err), "bad argument: %s", what);
+    return -1;
+}
+
+inline int round_up(int a, int b) { return (a + b - 1) / b * b; }
+
+// ---------------------------------------------------------------------------------------------------
+// workspace carving (all offsets 256-byte aligned)
+// ---------------------------------------------------------------------------------------------------
+struct Ws {
+    int n, npad, nb, d, p, q;
+    size_t esz;
+    size_t mat;          // elements per matrix
+    char* base;
+    size_t off_M, off_W, off_V, off_b, off_z, off_part, off_logdet, off_info, total;
+    int ntile_lower;
+};
+
+inline size_t align256(size_t x) { return (x + 255) & ~size_t(255); }
+
+inline Ws carve(int dtype, int n, int d, int p, int q, void* base) {
+    Ws w;
+    w.n = n; w.d = d; w.p = p; w.q = q;
+    w.npad = round_up(n, TS);
+    w.nb = w.npad / TS;
+    w.esz = dtype == LCGP_F64 ? 8 : 4;
+    w.mat = (size_t)w.npad * w.npad;
+    w.base = (char*)base;
+    w.ntile_lower = w.nb * (w.nb + 1) / 2;
+    size_t o = 0;
+    w.off_M = o; o = align256(o + w.mat * q * w.esz);
+    w.off_W = o; o = align256(o + w.mat * q * w.esz);
+    w.off_V = o; o = align256(o + w.mat * q * w.esz);
+    w.off_b = o; o = align256(o + (size_t)w.npad * q * w.esz);
+    w.off_z = o; o = align256(o + (size_t)w.npad * q * w.esz);
+    w.off_part = o; o = align256(o + (size_t)w.ntile_lower * q * (DMAX + 2) * sizeof(double));
+    w.off_logdet = o; o = align256(o + (size_t)q * sizeof(double));
+    w.off_info = o; o = align256(o + (size_t)q * sizeof(int));
+    w.total = o;
+    return w;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// MFMA wrappers.  A/B operand: lane l holds A[i = l & 15][k = l >> 4] / B[k = l >> 4][j = l & 15].
+// C/D: col = l & 15;  row = (l >> 4) + 4 * reg for f64,  (l >> 4) * 4 + reg for f32.
+// ---------------------------------------------------------------------------------------------------
+template <typename T> struct Mfma;
+template <> struct Mfma<double> {
+    typedef d4 acc_t;
+    static __device__ __forceinline__ acc_t run(double a, double b, acc_t c) {
+        return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ int row(int lane, int reg) { return (lane >> 4) + 4 * reg; }
+};
+template <> struct Mfma<float> {
+    typedef f4 acc_t;
+    static __device__ __forceinline__ acc_t run(float a, float b, acc_t c) {
+        return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ int row(int lane, int reg) { return (lane >> 4) * 4 + reg; }
+};
+
+__device__ __forceinline__ void tri_decode(int t, int& r, int& c) {
+    int rr = (int)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
+    while ((rr + 1) * (rr + 2) / 2 <= t) ++rr;
+    while (rr * (rr + 1) / 2 > t) --rr;
+    r = rr;
+    c = t - rr * (rr + 1) / 2;
+}
+
+// theta block accessors
+__device__ __forceinline__ const double* th_row(const double* theta, int d, int p, int k) {
+    return theta + (size_t)k * (d + 3 + p);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// K1: kernel build.   A_ij = delta_ij + D sr_i sr_j s ((1 - nt) C0_ij + nt delta_ij)
+//   C0 = prod_j (1 + S_j) exp(-sum_j S_j),  S_j = |x_i,j/ell_j - x_i',j/ell_j|      (covmat.py:35-53)
+// One 64x64 lower tile per workgroup; x rows/cols staged in LDS already divided by ell.
+// ---------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void build_kernel(T* __restrict__ M, size_t mat, int n, int npad, int d, int p,
+                                                    const T* __restrict__ x, const T* __restrict__ sr,
+                                                    const double* __restrict__ theta) {
+    __shared__ double xr[TS][DMAX + 1];
+    __shared__ double xc[TS][DMAX + 1];
+    __shared__ double srr[TS], src[TS];
+    const int k = blockIdx.y;
+    int r, c;
+    tri_decode(blockIdx.x, r, c);
+    const double* th = th_row(theta, d, p, k);
+    const double scale = th[d], nug = th[d + 1], D = th[d + 2];
+    const double nt = nug / (1.0 + nug);
+    const int tid = threadIdx.x;
+    for (int e = tid; e < TS * d; e += 256) {
+        int i = e / d, j = e - i * d;
+        int gi = r * TS + i, gj = c * TS + i;
+        xr[i][j] = gi < n ? (double)x[(size_t)gi * d + j] / th[j] : 0.0;
+        xc[i][j] = gj < n ? (double)x[(size_t)gj * d + j] / th[j] : 0.0;
+    }
+    if (tid < TS) {
+        int gi = r * TS + tid, gj = c * TS + tid;
+        srr[tid] = (sr && gi < n) ? (double)sr[gi] : 1.0;
+        src[tid] = (sr && gj < n) ? (double)sr[gj] : 1.0;
+    }
+    __syncthreads();
+    T* Mk = M + (size_t)k * mat;
+    const int j = tid & 63;
+    const int gj = c * TS + j;
+    for (int m = 0; m < 16; ++m) {
+        const int i = (tid >> 6) * 16 + m;
+        const int gi = r * TS + i;
+        double v;
+        if (gi < n && gj < n) {
+            double poly = 1.0, ssum = 0.0;
+            for (int jj = 0; jj < d; ++jj) {
+                double s = fabs(xr[i][jj] - xc[j][jj]);
+                poly *= 1.0 + s;
+                ssum -= s;
+            }
+            double c0 = poly * exp(ssum);
+            double dl = gi == gj ? 1.0 : 0.0;
+            v = dl + D * srr[i] * src[j] * scale * ((1.0 - nt) * c0 + nt * dl);
+        } else {
+            v = gi == gj ? 1.0 : 0.0;
+        }
+        Mk[(size_t)gi * npad + gj] = (T)v;
+    }
+}
+
+// rectangular Matern32 (covmat.py:31-55): out (n1 x n2) = scale ((1-nt) C0 + nt I[same]) o colscale^T.
+// Parameters come either by value (host call, lcgp_matern32) or from a device theta row (predict).
+struct ThetaArg { double v[DMAX + 2]; };
+
+template <typename T>
+__global__ __launch_bounds__(256) void cross_kernel(T* __restrict__ out, int ldo, int n1, int n2, int d,
+                                                    const T* __restrict__ x1, const T* __restrict__ x2,
+                                                    ThetaArg tv, const double* __restrict__ thp /*ell[d], scale, nug*/,
+                                                    int same, const T* __restrict__ colscale, int n1pad, int n2pad) {
+    __shared__ double xr[TS][DMAX + 1];
+    __shared__ double xc[TS][DMAX + 1];
+    __shared__ double cs[TS];
+    __shared__ double th[DMAX + 2];
+    const int r = blockIdx.y, c = blockIdx.x;
+    const int tid = threadIdx.x;
+    if (tid < d + 2) th[tid] = thp ? thp[tid] : tv.v[tid];
+    __syncthreads();
+    const double scale = th[d], nug = th[d + 1];
+    const double nt = nug / (1.0 + nug);
+    for (int e = tid; e < TS * d; e += 256) {
+        int i = e / d, j = e - i * d;
+        int gi = r * TS + i, gj = c * TS + i;
+        xr[i][j] = gi < n1 ? (double)x1[(size_t)gi * d + j] / th[j] : 0.0;
+        xc[i][j] = gj < n2 ? (double)x2[(size_t)gj * d + j] / th[j] : 0.0;
+    }
+    if (tid < TS) {
+        int gj = c * TS + tid;
+        cs[tid] = (colscale && gj < n2) ? (double)colscale[gj] : 1.0;
+    }
+    __syncthreads();
+    const int j = tid & 63;
+    const int gj = c * TS + j;
+    for (int m = 0; m < 16; ++m) {
+        const int i = (tid >> 6) * 16 + m;
+        const int gi = r * TS + i;
+        if (gi >= n1pad || gj >= n2pad) continue;
+        double v = 0.0;
+        if (gi < n1 && gj < n2) {
+            double poly = 1.0, ssum = 0.0;
+            for (int jj = 0; jj < d; ++jj) {
+                double s = fabs(xr[i][jj] - xc[j][jj]);
+                poly *= 1.0 + s;
+                ssum -= s;
+            }
+            double c0 = poly * exp(ssum);
+            double dl = (same && gi == gj) ? 1.0 : 0.0;
+            v = scale * ((1.0 - nt) * c0 + nt * dl) * cs[j];
+        }
+        out[(size_t)gi * ldo + gj] = (T)v;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// K2a: diagonal block.  Factorises the 64x64 block jb of M in LDS (L written back, upper part zeroed),
+// writes its inverse into W (upper part zero), adds sum log L_ii to logdet[k], records info[k].
+// One workgroup per component; accumulation in double also for float matrices.
+// ---------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void leaf_kernel(T* __restrict__ M, T* __restrict__ W, size_t mat, int npad, int jb,
+                                                   double* __restrict__ logdet, int* __restrict__ info) {
+    __shared__ double a[TS][TS + 1];
+    __shared__ double w[TS][TS + 1];
+    __shared__ double t[TS][TS + 1];
+    const int k = blockIdx.x;
+    const int tid = threadIdx.x;
+    T* Mb = M + (size_t)k * mat + (size_t)jb * TS * npad + (size_t)jb * TS;
+    T* Wb = W + (size_t)k * mat + (size_t)jb * TS * npad + (size_t)jb * TS;
+    const int cj = tid & 63;
+    const int rg = tid >> 6;
+    for (int m = 0; m < 16; ++m) {
+        int i = rg + 4 * m;
+        a[i][cj] = cj <= i ? (double)Mb[(size_t)i * npad + cj] : 0.0;
+        w[i][cj] = 0.0;
+    }
+    double ld_acc = 0.0;
+    int first_bad = 0;
+    for (int s = 0; s < TS; ++s) {
+        __syncthreads();
+        double akk = a[s][s];
+        if (!(akk > 0.0) && first_bad == 0) first_bad = jb * TS + s + 1;
+        double dk = sqrt(akk);
+        double inv = 1.0 / dk;
+        ld_acc += log(dk);
+        __syncthreads();
+        if (tid == s) a[s][s] = dk;
+        if (tid > s && tid < TS) a[tid][s] *= inv;
+        __syncthreads();
+        // trailing update of the lower part: (i, cj) with s < cj <= i
+        if (cj > s) {
+            double ljs = a[cj][s];
+            for (int m = 0; m < 16; ++m) {
+                int i = rg + 4 * m;
+                if (i >= cj) a[i][cj] -= a[i][s] * ljs;
+            }
+        }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        logdet[k] += ld_acc;
+        if (first_bad && info[k] == 0) info[k] = first_bad;
+    }
+    // ---- inverse of the 64x64 lower-triangular block, blocked by 16 ----
+    // (a) the four 16x16 diagonal blocks: thread = one column of one block
+    if (tid < TS) {
+        const int b0 = (tid >> 4) * 16;
+        const int cl = tid & 15;
+        const int cg = b0 + cl;
+        w[cg][cg] = 1.0 / a[cg][cg];
+        for (int i = cl + 1; i < 16; ++i) {
+            double s = 0.0;
+            for (int m = cl; m < i; ++m) s += a[b0 + i][b0 + m] * w[b0 + m][cg];
+            w[b0 + i][cg] = -s / a[b0 + i][b0 + i];
+        }
+    }
+    __syncthreads();
+    // (b) off-diagonal blocks by distance:  T_ab = sum_{m=b}^{a-1} L_am W_mb ;  W_ab = -W_aa T_ab
+    const int ei = tid >> 4, ej = tid & 15;
+    for (int dist = 1; dist < 4; ++dist) {
+        for (int bb = 0; bb + dist < 4; ++bb) {
+            const int ab = bb + dist;
+            double s = 0.0;
+            for (int mb = bb; mb < ab; ++mb)
+                for (int m = 0; m < 16; ++m) s += a[ab * 16 + ei][mb * 16 + m] * w[mb * 16 + m][bb * 16 + ej];
+            t[ab * 16 + ei][bb * 16 + ej] = s;
+        }
+        __syncthreads();
+        for (int bb = 0; bb + dist < 4; ++bb) {
+            const int ab = bb + dist;
+            double s = 0.0;
+            for (int m = 0; m <= ei; ++m) s += w[ab * 16 + ei][ab * 16 + m] * t[ab * 16 + m][bb * 16 + ej];
+            w[ab * 16 + ei][bb * 16 + ej] = -s;
+        }
+        __syncthreads();
+    }
+    for (int m = 0; m < 16; ++m) {
+        int i = rg + 4 * m;
+        Mb[(size_t)i * npad + cj] = (T)(cj <= i ? a[i][cj] : 0.0);
+        Wb[(size_t)i * npad + cj] = (T)(cj <= i ? w[i][cj] : 0.0);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Tile GEMM on MFMA:  C_tile (op)= alpha * sum_kt  Aop(kt) * Bop(kt)^T,   64x64 output per workgroup,
+// 4 waves each owning a 32x32 quadrant (2x2 MFMA 16x16x4 accumulators).  Operand tiles are 64 x 64
+// sub-blocks of M / W / V, read in either orientation:
+//   MK : element (m, k) at P[m * ld + k]      KM : element (m, k) at P[k * ld + m]
+// and staged in LDS as [k][m] (KT = 16 k rows per stage, double buffered through registers).
+// ---------------------------------------------------------------------------------------------------
+enum GemmOp { OP_TRMM_PANEL = 0, OP_SYRK = 1, OP_TRTRI_T = 2, OP_TRTRI_W = 3, OP_LAUUM = 4, OP_PRED_U = 5 };
+enum Lay { MK = 0, KM = 1 };
+
+struct GemmArgs {
+    const void* A; const void* B; void* C;     // component-0 bases
+    size_t sA, sB, sC;                          // per-component strides (elements)
+    int ldA, ldB, ldC;
+    int nb;                                     // number of 64-blocks
+    int p0, p1;                                 // op specific
+};
+
+template <typename T, int L>
+__device__ __forceinline__ void load_stage(const T* __restrict__ P, int ld, int ks, T (&reg)[4], int tid) {
+    if (L == MK) {
+        const int m = tid >> 2, kk = (tid & 3) * 4;
+        const T* src = P + (size_t)m * ld + ks + kk;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) reg[e] = src[e];
+    } else {
+        const int kq = tid >> 4, mm = (tid & 15) * 4;
+        const T* src = P + (size_t)(ks + kq) * ld + mm;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) reg[e] = src[e];
+    }
+}
+
+template <typename T, int L>
+__device__ __forceinline__ void store_stage(T* __restrict__ S, const T (&reg)[4], int tid) {
+    if (L == MK) {
+        const int m = tid >> 2, kk = (tid & 3) * 4;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) S[(kk + e) * LDM + m] = reg[e];
+    } else {
+        const int kq = tid >> 4, mm = (tid & 15) * 4;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) S[kq * LDM + mm + e] = reg[e];
+    }
+}
+
+template <typename T, int OP>
+__global__ __launch_bounds__(256) void tile_gemm(GemmArgs g) {
+    constexpr int LA = (OP == OP_LAUUM) ? KM : MK;
+    constexpr int LB = (OP == OP_TRTRI_T || OP == OP_TRTRI_W || OP == OP_LAUUM) ? KM : MK;
+    __shared__ T As[2][KT * LDM];
+    __shared__ T Bs[2][KT * LDM];
+
+    const int k = blockIdx.y;
+    const T* Ab = (const T*)g.A + (size_t)k * g.sA;
+    const T* Bb = (const T*)g.B + (size_t)k * g.sB;
+    T* Cb = (T*)g.C + (size_t)k * g.sC;
+
+    // ---- per-op tile decode: A0/B0 = first operand tiles, dA/dB = pointer step per kt, nkt, C tile ----
+    const T* A0; const T* B0; T* Ct;
+    size_t dA, dB;
+    int nkt;
+    double alpha = 1.0;
+    bool accumulate = false;
+    if constexpr (OP == OP_TRMM_PANEL) {
+        // M[r, j] = M[r, j] * W[j, j]^T for r = j+1+bid      (L21 = A21 L11^-T)
+        const int j = g.p0, r = j + 1 + blockIdx.x;
+        A0 = Ab + (size_t)r * TS * g.ldA + (size_t)j * TS; dA = 0;
+        B0 = Bb + (size_t)j * TS * g.ldB + (size_t)j * TS; dB = 0;
+        nkt = 1;
+        Ct = Cb + (size_t)r * TS * g.ldC + (size_t)j * TS;
+    } else if constexpr (OP == OP_SYRK) {
+        // M[r, c] -= sum_{kt in [p0, p1)} M[r, kt] M[c, kt]^T over the lower tiles with c >= p1
+        int rr, cc;
+        tri_decode(blockIdx.x, rr, cc);
+        const int r = g.p1 + rr, c = g.p1 + cc;
+        A0 = Ab + (size_t)r * TS * g.ldA + (size_t)g.p0 * TS; dA = TS;
+        B0 = Bb + (size_t)c * TS * g.ldB + (size_t)g.p0 * TS; dB = TS;
+        nkt = g.p1 - g.p0;
+        Ct = Cb + (size_t)r * TS * g.ldC + (size_t)c * TS;
+        alpha = -1.0; accumulate = true;
+    } else if constexpr (OP == OP_TRTRI_T || OP == OP_TRTRI_W) {
+        // level with block size mb = p0: pair pr covers block rows [2 pr mb, 2 pr mb + 2 mb)
+        const int mb = g.p0;
+        const int per = mb * mb;
+        const int pr = blockIdx.x / per, rem = blockIdx.x - pr * per;
+        const int rl = rem / mb, cl = rem - rl * mb;
+        const int C0 = 2 * pr * mb, R0 = C0 + mb;
+        if (R0 + rl >= g.nb) return;
+        if constexpr (OP == OP_TRTRI_T) {
+            // T[rl, cl] = sum_{kt = cl}^{mb-1} L21[rl, kt] W11[kt, cl]          (A from M, B from W, C into V)
+            A0 = Ab + (size_t)(R0 + rl) * TS * g.ldA + (size_t)(C0 + cl) * TS; dA = TS;
+            B0 = Bb + (size_t)(C0 + cl) * TS * g.ldB + (size_t)(C0 + cl) * TS; dB = (size_t)TS * g.ldB;
+            nkt = mb - cl;
+        } else {
+            // W21[rl, cl] = - sum_{kt = 0}^{rl} W22[rl, kt] T[kt, cl]            (A from W, B from V, C into W)
+            A0 = Ab + (size_t)(R0 + rl) * TS * g.ldA + (size_t)R0 * TS; dA = TS;
+            B0 = Bb + (size_t)R0 * TS * g.ldB + (size_t)(C0 + cl) * TS; dB = (size_t)TS * g.ldB;
+            nkt = rl + 1;
+            alpha = -1.0;
+        }
+        Ct = Cb + (size_t)(R0 + rl) * TS * g.ldC + (size_t)(C0 + cl) * TS;
+    } else if constexpr (OP == OP_LAUUM) {
+        // V[r, c] = sum_{kt = r}^{nb-1} W[kt, r]^T W[kt, c]
+        int r, c;
+        tri_decode(blockIdx.x, r, c);
+        // long k loops first: reverse the row order so the heaviest tiles are scheduled early
+        A0 = Ab + (size_t)r * TS * g.ldA + (size_t)r * TS; dA = (size_t)TS * g.ldA;
+        B0 = Bb + (size_t)r * TS * g.ldB + (size_t)c * TS; dB = (size_t)TS * g.ldB;
+        nkt = g.nb - r;
+        Ct = Cb + (size_t)r * TS * g.ldC + (size_t)c * TS;
+    } else {
+        // OP_PRED_U: U[m, r] = sum_{kt = 0}^{r} X[m, kt] W[r, kt]^T    (X = scaled cross covariance, n0pad x npad)
+        const int r = blockIdx.x % g.nb, m = blockIdx.x / g.nb;
+        A0 = Ab + (size_t)m * TS * g.ldA; dA = TS;
+        B0 = Bb + (size_t)r * TS * g.ldB; dB = TS;
+        nkt = r + 1;
+        Ct = Cb + (size_t)m * TS * g.ldC + (size_t)r * TS;
+    }
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm0 = (wave >> 1) * 32, wn0 = (wave & 1) * 32;
+    typedef typename Mfma<T>::acc_t acc_t;
+    acc_t acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[i][j][e] = 0;
+
+    const int nst = nkt * (TS / KT);
+    T ra[4], rb[4];
+    load_stage<T, LA>(A0, g.ldA, 0, ra, tid);
+    load_stage<T, LB>(B0, g.ldB, 0, rb, tid);
+    for (int s = 0; s < nst; ++s) {
+        const int buf = s & 1;
+        store_stage<T, LA>(As[buf], ra, tid);
+        store_stage<T, LB>(Bs[buf], rb, tid);
+        __syncthreads();
+        if (s + 1 < nst) {
+            const int kt = (s + 1) / (TS / KT), ks = ((s + 1) % (TS / KT)) * KT;
+            load_stage<T, LA>(A0 + (size_t)kt * dA, g.ldA, ks, ra, tid);
+            load_stage<T, LB>(B0 + (size_t)kt * dB, g.ldB, ks, rb, tid);
+        }
+        const T* as = As[buf];
+        const T* bs = Bs[buf];
+#pragma unroll
+        for (int kk = 0; kk < KT / 4; ++kk) {
+            const int krow = (kk * 4 + (lane >> 4)) * LDM;
+            T a0 = as[krow + wm0 + (lane & 15)];
+            T a1 = as[krow + wm0 + 16 + (lane & 15)];
+            T b0 = bs[krow + wn0 + (lane & 15)];
+            T b1 = bs[krow + wn0 + 16 + (lane & 15)];
+            acc[0][0] = Mfma<T>::run(a0, b0, acc[0][0]);
+            acc[0][1] = Mfma<T>::run(a0, b1, acc[0][1]);
+            acc[1][0] = Mfma<T>::run(a1, b0, acc[1][0]);
+            acc[1][1] = Mfma<T>::run(a1, b1, acc[1][1]);
+        }
+    }
+    // the panel TRMM overwrites its own A tile: every wave must be done reading it (it is: all stages
+    // were staged through LDS before the last __syncthreads) -- C is written only after the k loop.
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int row = wm0 + mi * 16 + Mfma<T>::row(lane, e);
+                const int col = wn0 + ni * 16 + (lane & 15);
+                T* dst = Ct + (size_t)row * g.ldC + col;
+                double v = alpha * (double)acc[mi][ni][e];
+                if (accumulate) v += (double)*dst;
+                *dst = (T)v;
+            }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// b_k[i] = sum_a Y[a, i] psi_k[a]   (lcgp.py:646 + 657-658 collapsed; lcgp.py:608-610 for rep)
+// ---------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void bvec_kernel(T* __restrict__ b, int n, int npad, int d, int p, const T* __restrict__ Y,
+                            const double* __restrict__ theta) {
+    const int k = blockIdx.y;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= npad) return;
+    const double* psi = th_row(theta, d, p, k) + d + 3;
+    double s = 0.0;
+    if (i < n)
+        for (int a = 0; a < p; ++a) s += (double)Y[(size_t)a * n + i] * psi[a];
+    b[(size_t)k * npad + i] = (T)s;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// z = A^-1 b with A^-1 stored as lower 64x64 tiles.  One workgroup per (row block r, component):
+//   z_r = sum_{c <= r} V[r, c] b_c  +  sum_{r' > r} V[r', r]^T b_r'            (fixed summation order)
+// ---------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void symv_kernel(const T* __restrict__ V, size_t mat, int npad, int nb,
+                                                   const T* __restrict__ b, T* __restrict__ z) {
+    __shared__ double red[4][TS];
+    __shared__ double part1[TS];
+    const int k = blockIdx.y, r = blockIdx.x;
+    const T* Vk = V + (size_t)k * mat;
+    const T* bk = b + (size_t)k * npad;
+    const int tid = threadIdx.x;
+    // part 1: row i = tid >> 2, 16 columns per tile per thread
+    {
+        const int i = tid >> 2, q4 = tid & 3;
+        const T* row = Vk + (size_t)(r * TS + i) * npad;
+        double s = 0.0;
+        for (int c = 0; c <= r; ++c) {
+            const T* v = row + c * TS + q4 * 16;
+            const T* bb = bk + c * TS + q4 * 16;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) s += (double)v[e] * (double)bb[e];
+        }
+        s += __shfl_xor(s, 1);
+        s += __shfl_xor(s, 2);
+        if (q4 == 0) part1[i] = s;
+    }
+    // part 2: column j = tid & 63 of the tiles below, rows g, g+4, ...
+    {
+        const int j = tid & 63, gq = tid >> 6;
+        double s = 0.0;
+        for (int rp = r + 1; rp < nb; ++rp) {
+            const T* base = Vk + (size_t)(rp * TS) * npad + r * TS + j;
+            const T* bb = bk + rp * TS;
+            for (int m = gq; m < TS; m += 4) s += (double)base[(size_t)m * npad] * (double)bb[m];
+        }
+        red[gq][j] = s;
+    }
+    __syncthreads();
+    if (tid < TS) {
+        double s = part1[tid] + ((red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]));
+        z[(size_t)k * npad + r * TS + tid] = (T)s;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// K5: fused gradient contraction over the lower tiles of A^-1 (HBM read once):
+//   G_ij = sr_i sr_j (D/2 Ainv_ij - z_i z_j / 2),  weight 2 off the diagonal,
+//   part[0..d-1] = sum w G C0 S_j^2/(1+S_j),  part[d] = sum w G C0,  part[d+1] = sum_i G_ii
+// C0 and S_j are recomputed from x in LDS.  Per-tile partial sums, reduced later in fixed order.
+// ---------------------------------------------------------------------------------------------------
+template <typename T, int DD>
+__global__ __launch_bounds__(256) void grad_kernel(const T* __restrict__ V, size_t mat, int n, int npad, int d, int p,
+                                                   const T* __restrict__ x, const T* __restrict__ sr,
+                                                   const T* __restrict__ z, const double* __restrict__ theta,
+                                                   double* __restrict__ part, int ntile) {
+    __shared__ double xr[TS][DD + 1];
+    __shared__ double xc[TS][DD + 1];
+    __shared__ double zr[TS], zc[TS], srr[TS], src[TS];
+    __shared__ double red[4][DD + 2];
+    const int k = blockIdx.y;
+    int r, c;
+    tri_decode(blockIdx.x, r, c);
+    const double* th = th_row(theta, d, p, k);
+    const double D = th[d + 2];
+    const int tid = threadIdx.x;
+    for (int e = tid; e < TS * d; e += 256) {
+        int i = e / d, j = e - i * d;
+        int gi = r * TS + i, gj = c * TS + i;
+        xr[i][j] = gi < n ? (double)x[(size_t)gi * d + j] / th[j] : 0.0;
+        xc[i][j] = gj < n ? (double)x[(size_t)gj * d + j] / th[j] : 0.0;
+    }
+    if (tid < TS) {
+        int gi = r * TS + tid, gj = c * TS + tid;
+        zr[tid] = (double)z[(size_t)k * npad + gi];
+        zc[tid] = (double)z[(size_t)k * npad + gj];
+        srr[tid] = (sr && gi < n) ? (double)sr[gi] : 1.0;
+        src[tid] = (sr && gj < n) ? (double)sr[gj] : 1.0;
+    }
+    __syncthreads();
+    double acc[DD + 2];
+#pragma unroll
+    for (int e = 0; e < DD + 2; ++e) acc[e] = 0.0;
+    const T* Vk = V + (size_t)k * mat;
+    const int j = tid & 63;
+    const int gj = c * TS + j;
+    for (int m = 0; m < 16; ++m) {
+        const int i = (tid >> 6) * 16 + m;
+        const int gi = r * TS + i;
+        if (gi >= n || gj >= n || gj > gi) continue;
+        const double ainv = (double)Vk[(size_t)gi * npad + gj];
+        const double wgt = gi == gj ? 1.0 : 2.0;
+        const double G = wgt * srr[i] * src[j] * (0.5 * D * ainv - 0.5 * zr[i] * zc[j]);
+        double poly = 1.0, ssum = 0.0;
+        double tt[DD];
+#pragma unroll
+        for (int jj = 0; jj < DD; ++jj) {
+            if (jj < d) {
+                double s = fabs(xr[i][jj] - xc[j][jj]);
+                poly *= 1.0 + s;
+                ssum -= s;
+                tt[jj] = s * s / (1.0 + s);
+            } else {
+                tt[jj] = 0.0;
+            }
+        }
+        const double gc0 = G * poly * exp(ssum);
+#pragma unroll
+        for (int jj = 0; jj < DD; ++jj) acc[jj] += gc0 * tt[jj];
+        acc[DD] += gc0;
+        if (gi == gj) acc[DD + 1] += G;
+    }
+    // deterministic block reduction: wave butterfly, then 4 waves through LDS
+#pragma unroll
+    for (int e = 0; e < DD + 2; ++e) {
+        double v = acc[e];
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+        acc[e] = v;
+    }
+    if ((tid & 63) == 0)
+#pragma unroll
+        for (int e = 0; e < DD + 2; ++e) red[tid >> 6][e] = acc[e];
+    __syncthreads();
+    if (tid < d + 2) {
+        const int e = tid < d ? tid : (DD + tid - d);
+        double* dst = part + ((size_t)k * ntile + blockIdx.x) * (DMAX + 2);
+        dst[tid] = (red[0][e] + red[1][e]) + (red[2][e] + red[3][e]);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// finalize: per component, reduce the tile partials, quad = b.(b - z), gsig_a = Y[a,:].(b - z), pack output.
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double block_sum(double v, double* sh /*>= 4*/, int tid) {
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    __syncthreads();
+    if ((tid & 63) == 0) sh[tid >> 6] = v;
+    __syncthreads();
+    return (sh[0] + sh[1]) + (sh[2] + sh[3]);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void finalize_kernel(int n, int npad, int d, int p, int ntile,
+                                                       const T* __restrict__ Y, const T* __restrict__ b,
+                                                       const T* __restrict__ z, const double* __restrict__ part,
+                                                       const double* __restrict__ logdet, const int* __restrict__ info,
+                                                       const double* __restrict__ theta, double* __restrict__ out) {
+    __shared__ double sh[4];
+    const int k = blockIdx.x;
+    const int tid = threadIdx.x;
+    const double* th = th_row(theta, d, p, k);
+    double* o = out + (size_t)k * (d + 5 + p);
+    const T* bk = b + (size_t)k * npad;
+    const T* zk = z + (size_t)k * npad;
+    // tile partials
+    double sums[DMAX + 2];
+    for (int e = 0; e < d + 2; ++e) {
+        double v = 0.0;
+        for (int t = tid; t < ntile; t += 256) v += part[((size_t)k * ntile + t) * (DMAX + 2) + e];
+        sums[e] = block_sum(v, sh, tid);
+    }
+    double v = 0.0;
+    for (int i = tid; i < n; i += 256) v += (double)bk[i] * ((double)bk[i] - (double)zk[i]);
+    const double quad = block_sum(v, sh, tid);
+    const double scale = th[d], nug = th[d + 1];
+    const double nt = nug / (1.0 + nug);
+    if (tid == 0) {
+        o[0] = logdet[k];
+        o[1] = quad;
+        o[2] = (double)info[k];
+        for (int j = 0; j < d; ++j) o[3 + j] = scale * (1.0 - nt) / th[j] * sums[j];
+        o[3 + d] = (1.0 - nt) * sums[d] + nt * sums[d + 1];
+        o[4 + d] = scale * (sums[d + 1] - sums[d]) / ((1.0 + nug) * (1.0 + nug));
+    }
+    for (int a = 0; a < p; ++a) {
+        double s = 0.0;
+        for (int i = tid; i < n; i += 256) s += (double)Y[(size_t)a * n + i] * ((double)bk[i] - (double)zk[i]);
+        s = block_sum(s, sh, tid);
+        if (tid == 0) o[5 + d + a] = s;
+    }
+}
+
+// small helpers ----------------------------------------------------------------------------------------
+__global__ void zero_stats_kernel(double* logdet, int* info, int q) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < q) { logdet[i] = 0.0; info[i] = 0; }
+}
+
+__global__ void copy_stats_kernel(const double* logdet, const int* info, double* ld_out, int* info_out, int q) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < q) { if (ld_out) ld_out[i] = logdet[i]; if (info_out) info_out[i] = info[i]; }
+}
+
+template <typename T>
+__global__ void fetch_kernel(const T* __restrict__ src, int npad, int n, T* __restrict__ dst) {
+    int j = blockIdx.x * blockDim.x + threadIdx.x, i = blockIdx.y;
+    if (j >= n) return;
+    dst[(size_t)i * n + j] = j <= i ? src[(size_t)i * npad + j] : src[(size_t)j * npad + i];
+}
+
+// ghat[m] = sum_i X[m, i] z_i ;  gvar[m] = scale - D * sum_i U[m, i]^2        (one wave per row m)
+template <typename T>
+__global__ __launch_bounds__(64) void pred_reduce_kernel(const T* __restrict__ X, const T* __restrict__ U, int ld, int n,
+                                                         const T* __restrict__ z, const double* __restrict__ th, int d,
+                                                         double* __restrict__ ghat, double* __restrict__ gvar) {
+    const int m = blockIdx.x, lane = threadIdx.x;
+    const double scale = th[d], D = th[d + 2];
+    double s1 = 0.0, s2 = 0.0;
+    for (int i = lane; i < n; i += 64) {
+        double u = (double)U[(size_t)m * ld + i];
+        s1 += (double)X[(size_t)m * ld + i] * (double)z[i];
+        s2 += u * u;
+    }
+    for (int off = 32; off > 0; off >>= 1) { s1 += __shfl_xor(s1, off); s2 += __shfl_xor(s2, off); }
+    if (lane == 0) { ghat[m] = s1; gvar[m] = scale - D * s2; }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// host-side drivers (enqueue only)
+// ---------------------------------------------------------------------------------------------------
+#define CHECK_LAUNCH(what)                                  \
+    do {                                                    \
+        hipError_t e__ = hipGetLastError();                 \
+        if (e__ != hipSuccess) return fail(what, e__);      \
+    } while (0)
+
+template <typename T>
+int do_build(hipStream_t st, const Ws& w, const void* x, const void* sr, const double* theta) {
+    dim3 grid(w.ntile_lower, w.q);
+    hipLaunchKernelGGL((build_kernel<T>), grid, dim3(256), 0, st, (T*)(w.base + w.off_M), w.mat, w.n, w.npad, w.d, w.p,
+                       (const T*)x, (const T*)sr, theta);
+    CHECK_LAUNCH("build_kernel");
+    return 0;
+}
+
+template <typename T, int OP>
+int launch_gemm(hipStream_t st, const GemmArgs& g, int ntiles, int q) {
+    if (ntiles <= 0) return 0;
+    hipLaunchKernelGGL((tile_gemm<T, OP>), dim3(ntiles, q), dim3(256), 0, st, g);
+    CHECK_LAUNCH("tile_gemm");
+    return 0;
+}
+
+template <typename T>
+int do_potrf(hipStream_t st, const Ws& w) {
+    T* M = (T*)(w.base + w.off_M);
+    T* W = (T*)(w.base + w.off_W);
+    double* logdet = (double*)(w.base + w.off_logdet);
+    int* info = (int*)(w.base + w.off_info);
+    hipLaunchKernelGGL(zero_stats_kernel, dim3((w.q + 63) / 64), dim3(64), 0, st, logdet, info, w.q);
+    CHECK_LAUNCH("zero_stats");
+    for (int j = 0; j < w.nb; ++j) {
+        hipLaunchKernelGGL((leaf_kernel<T>), dim3(w.q), dim3(256), 0, st, M, W, w.mat, w.npad, j, logdet, info);
+        CHECK_LAUNCH("leaf_kernel");
+        const int rest = w.nb - 1 - j;
+        if (rest <= 0) break;
+        GemmArgs g;
+        g.A = M; g.B = W; g.C = M; g.sA = g.sB = g.sC = w.mat; g.ldA = g.ldB = g.ldC = w.npad; g.nb = w.nb;
+        g.p0 = j; g.p1 = 0;
+        int rc = launch_gemm<T, OP_TRMM_PANEL>(st, g, rest, w.q);
+        if (rc) return rc;
+        g.A = M; g.B = M; g.C = M; g.p0 = j; g.p1 = j + 1;
+        rc = launch_gemm<T, OP_SYRK>(st, g, rest * (rest + 1) / 2, w.q);
+        if (rc) return rc;
+    }
+    return 0;
+}
+
+template <typename T>
+int do_potri(hipStream_t st, const Ws& w) {
+    T* M = (T*)(w.base + w.off_M);
+    T* W = (T*)(w.base + w.off_W);
+    T* V = (T*)(w.base + w.off_V);
+    GemmArgs g;
+    g.sA = g.sB = g.sC = w.mat; g.ldA = g.ldB = g.ldC = w.npad; g.nb = w.nb; g.p1 = 0;
+    for (int mb = 1; mb < w.nb; mb *= 2) {
+        const int pairs = (w.nb + 2 * mb - 1) / (2 * mb);
+        g.p0 = mb;
+        g.A = M; g.B = W; g.C = V;
+        int rc = launch_gemm<T, OP_TRTRI_T>(st, g, pairs * mb * mb, w.q);
+        if (rc) return rc;
+        g.A = W; g.B = V; g.C = W;
+        rc = launch_gemm<T, OP_TRTRI_W>(st, g, pairs * mb * mb, w.q);
+        if (rc) return rc;
+    }
+    g.A = W; g.B = W; g.C = V; g.p0 = 0;
+    return launch_gemm<T, OP_LAUUM>(st, g, w.ntile_lower, w.q);
+}
+
+template <typename T, int DD>
+void launch_grad(hipStream_t st, const Ws& w, const void* x, const void* sr, const double* theta) {
+    hipLaunchKernelGGL((grad_kernel<T, DD>), dim3(w.ntile_lower, w.q), dim3(256), 0, st, (const T*)(w.base + w.off_V),
+                       w.mat, w.n, w.npad, w.d, w.p, (const T*)x, (const T*)sr, (const T*)(w.base + w.off_z), theta,
+                       (double*)(w.base + w.off_part), w.ntile_lower);
+}
+
+template <typename T>
+int do_nll_grad(hipStream_t st, const Ws& w, const void* x, const void* Y, const void* sr, const double* theta,
+                double* out) {
+    int rc = do_build<T>(st, w, x, sr, theta);
+    if (rc) return rc;
+    T* b = (T*)(w.base + w.off_b);
+    T* z = (T*)(w.base + w.off_z);
+    hipLaunchKernelGGL((bvec_kernel<T>), dim3((w.npad + 255) / 256, w.q), dim3(256), 0, st, b, w.n, w.npad, w.d, w.p,
+                       (const T*)Y, theta);
+    CHECK_LAUNCH("bvec_kernel");
+    rc = do_potrf<T>(st, w);
+    if (rc) return rc;
+    rc = do_potri<T>(st, w);
+    if (rc) return rc;
+    hipLaunchKernelGGL((symv_kernel<T>), dim3(w.nb, w.q), dim3(256), 0, st, (const T*)(w.base + w.off_V), w.mat, w.npad,
+                       w.nb, (const T*)b, z);
+    CHECK_LAUNCH("symv_kernel");
+    if (w.d <= 2) launch_grad<T, 2>(st, w, x, sr, theta);
+    else if (w.d <= 4) launch_grad<T, 4>(st, w, x, sr, theta);
+    else if (w.d <= 6) launch_grad<T, 6>(st, w, x, sr, theta);
+    else if (w.d <= 10) launch_grad<T, 10>(st, w, x, sr, theta);
+    else launch_grad<T, DMAX>(st, w, x, sr, theta);
+    CHECK_LAUNCH("grad_kernel");
+    hipLaunchKernelGGL((finalize_kernel<T>), dim3(w.q), dim3(256), 0, st, w.n, w.npad, w.d, w.p, w.ntile_lower,
+                       (const T*)Y, (const T*)b, (const T*)z, (const double*)(w.base + w.off_part),
+                       (const double*)(w.base + w.off_logdet), (const int*)(w.base + w.off_info), theta, out);
+    CHECK_LAUNCH("finalize_kernel");
+    return 0;
+}
+
+int check_common(int dtype, int n, int d, int p, int q) {
+    if (dtype != LCGP_F64 && dtype != LCGP_F32) return bad("dtype must be 0 (f64) or 1 (f32)");
+    if (n < 1) return bad("n < 1");
+    if (d < 1 || d > DMAX) return bad("d must be in [1, 16]");
+    if (p < 1) return bad("p < 1");
+    if (q < 1 || q > 65535) return bad("q_local must be in [1, 65535]");
+    return 0;
+}
+
+template <typename T>
+int do_matern(hipStream_t st, int n1, int n2, int d, const void* x1, const void* x2, const ThetaArg& th, int same,
+              void* out) {
+    dim3 grid((n2 + TS - 1) / TS, (n1 + TS - 1) / TS);
+    hipLaunchKernelGGL((cross_kernel<T>), grid, dim3(256), 0, st, (T*)out, n2, n1, n2, d, (const T*)x1, (const T*)x2, th,
+                       (const double*)nullptr, same, (const T*)nullptr, n1, n2);
+    CHECK_LAUNCH("cross_kernel");
+    return 0;
+}
+
+template <typename T>
+int do_predict(hipStream_t st, const Ws& w, const void* x, const void* sr, const double* theta, int n0, const void* x0,
+               int same, void* scratch, double* ghat, double* gvar) {
+    const int n0pad = round_up(n0, TS);
+    T* X = (T*)scratch;                                   // n0pad x npad : c0k o sr^T (zero padded)
+    T* U = X + (size_t)n0pad * w.npad;                    // n0pad x npad : X W^T = (L^-1 X^T)^T
+    ThetaArg dummy;
+    memset(&dummy, 0, sizeof(dummy));
+    for (int k = 0; k < w.q; ++k) {
+        const double* th = theta + (size_t)k * (w.d + 3 + w.p);
+        dim3 grid(w.nb, n0pad / TS);
+        hipLaunchKernelGGL((cross_kernel<T>), grid, dim3(256), 0, st, X, w.npad, n0, w.n, w.d, (const T*)x0, (const T*)x,
+                           dummy, th, same, (const T*)sr, n0pad, w.npad);
+        CHECK_LAUNCH("cross_kernel");
+        GemmArgs g;
+        g.A = X; g.B = (const T*)(w.base + w.off_W) + (size_t)k * w.mat; g.C = U;
+        g.sA = g.sB = g.sC = 0; g.ldA = g.ldB = g.ldC = w.npad; g.nb = w.nb; g.p0 = g.p1 = 0;
+        int rc = launch_gemm<T, OP_PRED_U>(st, g, (n0pad / TS) * w.nb, 1);
+        if (rc) return rc;
+        hipLaunchKernelGGL((pred_reduce_kernel<T>), dim3(n0), dim3(64), 0, st, (const T*)X, (const T*)U, w.npad, w.n,
+                           (const T*)(w.base + w.off_z) + (size_t)k * w.npad, th, w.d, ghat + (size_t)k * n0,
+                           gvar + (size_t)k * n0);
+        CHECK_LAUNCH("pred_reduce_kernel");
+    }
+    return 0;
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------------
+// C ABI
+// ---------------------------------------------------------------------------------------------------
+extern "C" {
+
+int lcgp_version(void) { return LCGP_VERSION; }
+const char* lcgp_last_error(void) { return g_err; }
+int lcgp_theta_width(int d, int p) { return d + 3 + p; }
+int lcgp_out_width(int d, int p) { return d + 5 + p; }
+
+int lcgp_workspace_bytes(int dtype, int n, int d, int p, int q_local, size_t* bytes) {
+    int rc = check_common(dtype, n, d, p, q_local);
+    if (rc) return rc;
+    if (!bytes) return bad("bytes is NULL");
+    *bytes = carve(dtype, n, d, p, q_local, nullptr).total;
+    return 0;
+}
+
+int lcgp_matern32(void* stream, int dtype, int n1, int n2, int d, const void* x1, const void* x2, const double* ell,
+                  double scale, double nug, int same, void* out) {
+    if (dtype != LCGP_F64 && dtype != LCGP_F32) return bad("dtype must be 0 (f64) or 1 (f32)");
+    if (n1 < 1 || n2 < 1) return bad("n1/n2 < 1");
+    if (d < 1 || d > DMAX) return bad("d must be in [1, 16]");
+    if (!x1 || !x2 || !ell || !out) return bad("NULL pointer");
+    ThetaArg th;
+    memset(&th, 0, sizeof(th));
+    for (int j = 0; j < d; ++j) th.v[j] = ell[j];
+    th.v[d] = scale;
+    th.v[d + 1] = nug;
+    hipStream_t st = (hipStream_t)stream;
+    return dtype == LCGP_F64 ? do_matern<double>(st, n1, n2, d, x1, x2, th, same, out)
+                             : do_matern<float>(st, n1, n2, d, x1, x2, th, same, out);
+}
+
+int lcgp_kernel_build(void* stream, int dtype, int n, int d, int p, int q_local, const void* x, const void* sr,
+                      const double* theta, void* workspace) {
+    int rc = check_common(dtype, n, d, p, q_local);
+    if (rc) return rc;
+    if (!x || !theta || !workspace) return bad("NULL pointer");
+    Ws w = carve(dtype, n, d, p, q_local, workspace);
+    return dtype == LCGP_F64 ? do_build<double>((hipStream_t)stream, w, x, sr, theta)
+                             : do_build<float>((hipStream_t)stream, w, x, sr, theta);
+}
+
+int lcgp_potrf_logdet(void* stream, int dtype, int n, int d, int p, int q_local, void* workspace, double* half_logdet,
+                      int* info) {
+    int rc = check_common(dtype, n, d, p, q_local);
+    if (rc) return rc;
+    if (!workspace) return bad("NULL workspace");
+    Ws w = carve(dtype, n, d, p, q_local, workspace);
+    hipStream_t st = (hipStream_t)stream;
+    rc = dtype == LCGP_F64 ? do_potrf<double>(st, w) : do_potrf<float>(st, w);
+    if (rc) return rc;
+    if (half_logdet || info) {
+        hipLaunchKernelGGL(copy_stats_kernel, dim3((q_local + 63) / 64), dim3(64), 0, st,
+                           (const double*)(w.base + w.off_logdet), (const int*)(w.base + w.off_info), half_logdet, info,
+                           q_local);
+        CHECK_LAUNCH("copy_stats");
+    }
+    return 0;
+}
+
+int lcgp_potri(void* stream, int dtype, int n, int d, int p, int q_local, void* workspace) {
+    int rc = check_common(dtype, n, d, p, q_local);
+    if (rc) return rc;
+    if (!workspace) return bad("NULL workspace");
+    Ws w = carve(dtype, n, d, p, q_local, workspace);
+    return dtype == LCGP_F64 ? do_potri<double>((hipStream_t)stream, w) : do_potri<float>((hipStream_t)stream, w);
+}
+
+int lcgp_fetch_matrix(void* stream, int dtype, int n, int d, int p, int q_local, const void* workspace, int which, int k,
+                      void* out) {
+    int rc = check_common(dtype, n, d, p, q_local);
+    if (rc) return rc;
+    if (!workspace || !out) return bad("NULL pointer");
+    if (which < 0 || which > 2 || k < 0 || k >= q_local) return bad("which/k out of range");
+    Ws w = carve(dtype, n, d, p, q_local, (void*)workspace);
+    size_t off = which == 0 ? w.off_M : (which == 1 ? w.off_W : w.off_V);
+    dim3 grid((n + 255) / 256, n);
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == LCGP_F64)
+        hipLaunchKernelGGL((fetch_kernel<double>), grid, dim3(256), 0, st,
+                           (const double*)(w.base + off) + (size_t)k * w.mat, w.npad, n, (double*)out);
+    else
+        hipLaunchKernelGGL((fetch_kernel<float>), grid, dim3(256), 0, st,
+                           (const float*)(w.base + off) + (size_t)k * w.mat, w.npad, n, (float*)out);
+    CHECK_LAUNCH("fetch_kernel");
+    return 0;
+}
+
+int lcgp_nll_grad(void* stream, int dtype, int n, int d, int p, int q_local, const void* x, const void* Y,
+                  const void* sr, const double* theta, void* workspace, double* out) {
+    int rc = check_common(dtype, n, d, p, q_local);
+    if (rc) return rc;
+    if (!x || !Y || !theta || !workspace || !out) return bad("NULL pointer");
+    Ws w = carve(dtype, n, d, p, q_local, workspace);
+    return dtype == LCGP_F64 ? do_nll_grad<double>((hipStream_t)stream, w, x, Y, sr, theta, out)
+                             : do_nll_grad<float>((hipStream_t)stream, w, x, Y, sr, theta, out);
+}
+
+int lcgp_predict(void* stream, int dtype, int n, int d, int p, int q_local, const void* x, const void* sr,
+                 const double* theta, const void* workspace, int n0, const void* x0, int same, void* scratch,
+                 double* ghat, double* gvar) {
+    int rc = check_common(dtype, n, d, p, q_local);
+    if (rc) return rc;
+    if (n0 < 1) return bad("n0 < 1");
+    if (!x || !theta || !workspace || !x0 || !scratch || !ghat || !gvar) return bad("NULL pointer");
+    Ws w = carve(dtype, n, d, p, q_local, (void*)workspace);
+    hipStream_t st = (hipStream_t)stream;
+    return dtype == LCGP_F64 ? do_predict<double>(st, w, x, sr, theta, n0, x0, same, scratch, ghat, gvar)
+                             : do_predict<float>(st, w, x, sr, theta, n0, x0, same, scratch, ghat, gvar);
+}
+
+}  // extern "C"
