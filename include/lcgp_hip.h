@@ -78,10 +78,19 @@ int lcgp_potrf_logdet(void* stream, int dtype, int n, int d, int p, int q_local,
  * U diag(.) U^T products of lcgp.py:654 / 705-715 and cholesky_solve with identity (lcgp.py:785). */
 int lcgp_potri(void* stream, int dtype, int n, int d, int p, int q_local, void* workspace);
 
+/* the two stages of lcgp_potri on their own (for per-kernel timing): W = L^-1 (level-parallel triangular
+ * products), then A^-1 = W^T W (a single launch of the MFMA tile kernel; n^3/3 flops per component). */
+int lcgp_trtri(void* stream, int dtype, int n, int d, int p, int q_local, void* workspace);
+int lcgp_lauum(void* stream, int dtype, int n, int d, int p, int q_local, void* workspace);
+
 /* copies matrix `which` (0 = A/L, 1 = L^-1, 2 = A^-1) of local component k out of the workspace as a
  * dense n x n row-major matrix (lower triangle valid, upper triangle mirrored); for tests. */
 int lcgp_fetch_matrix(void* stream, int dtype, int n, int d, int p, int q_local, const void* workspace,
                       int which, int k, void* out /*n x n*/);
+
+/* copies vector `which` (0 = b_k, 1 = z_k = A_k^-1 b_k) of local component k (n elements of dtype). */
+int lcgp_fetch_vector(void* stream, int dtype, int n, int d, int p, int q_local, const void* workspace,
+                      int which, int k, void* out /*n*/);
 
 /* The whole hot path for q_local components: build + Cholesky + inverse + z = A^-1 b + fused gradient
  * contraction.  Replaces one call of LCGP.neglpost (lcgp.py:635-666) or LCGP.neglpost_rep

@@ -1,0 +1,94 @@
+"""ctypes binding of liblcgp_hip.so (the C ABI declared in include/lcgp_hip.h).
+
+The library is built in-tree by `make` / `__graft_entry__.build()`.  There is NO CPU fallback: if the
+shared object is missing or no GPU is visible, every hot-path call raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_ROOT = os.path.dirname(_HERE)
+LIB_PATH = os.path.join(_HERE, "liblcgp_hip.so")
+SRC_PATH = os.path.join(_HERE, "csrc", "lcgp_hip.hip")
+HDR_PATH = os.path.join(_ROOT, "include", "lcgp_hip.h")
+
+F64, F32 = 0, 1
+
+# every symbol include/lcgp_hip.h declares: name -> (restype, argtypes)
+_vp, _i, _d = C.c_void_p, C.c_int, C.c_double
+SIGNATURES = {
+    "lcgp_version": (_i, []),
+    "lcgp_last_error": (C.c_char_p, []),
+    "lcgp_theta_width": (_i, [_i, _i]),
+    "lcgp_out_width": (_i, [_i, _i]),
+    "lcgp_workspace_bytes": (_i, [_i, _i, _i, _i, _i, C.POINTER(C.c_size_t)]),
+    "lcgp_matern32": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, C.POINTER(_d), _d, _d, _i, _vp]),
+    "lcgp_kernel_build": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
+    "lcgp_potrf_logdet": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
+    "lcgp_potri": (_i, [_vp, _i, _i, _i, _i, _i, _vp]),
+    "lcgp_trtri": (_i, [_vp, _i, _i, _i, _i, _i, _vp]),
+    "lcgp_lauum": (_i, [_vp, _i, _i, _i, _i, _i, _vp]),
+    "lcgp_fetch_matrix": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _i, _i, _vp]),
+    "lcgp_fetch_vector": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _i, _i, _vp]),
+    "lcgp_nll_grad": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "lcgp_predict": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp, _i, _vp, _vp, _vp]),
+}
+
+_lib = None
+
+
+def needs_build() -> bool:
+    if not os.path.exists(LIB_PATH):
+        return True
+    t = os.path.getmtime(LIB_PATH)
+    return any(os.path.exists(s) and os.path.getmtime(s) > t for s in (SRC_PATH, HDR_PATH))
+
+
+def build_library(force: bool = False, verbose: bool = False) -> str:
+    """hipcc --offload-arch=gfx950 -> lcgp_amd/liblcgp_hip.so (cross-compiles without a GPU)."""
+    if not force and not needs_build():
+        return LIB_PATH
+    cmd = ["hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-shared", "-o", LIB_PATH, SRC_PATH]
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    if verbose or res.returncode != 0:
+        print(" ".join(cmd))
+        print(res.stdout, res.stderr)
+    if res.returncode != 0:
+        raise RuntimeError("building liblcgp_hip.so failed:\n" + res.stderr)
+    return LIB_PATH
+
+
+def load():
+    """Returns the loaded library with argtypes set; raises if it is not there (no fallback)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            "lcgp_amd: %s is missing -- build it with `make` or `python -c 'import __graft_entry__ as g; g.build()'`. "
+            "The LCGP hot path has no CPU fallback." % LIB_PATH)
+    # torch must own the HIP runtime of the process (same SONAME, loaded first)
+    import torch  # noqa: F401
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError here = header and library out of sync
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str):
+    if rc != 0:
+        msg = load().lcgp_last_error().decode("utf-8", "replace")
+        raise RuntimeError("%s failed (rc=%d): %s" % (what, rc, msg))
+
+
+def require_gpu():
+    import torch
+    if not torch.cuda.is_available():
+        raise RuntimeError("lcgp_amd: the LCGP hot path runs on an AMD GPU (gfx950) only; no GPU is visible "
+                           "and there is deliberately no CPU fallback.")

@@ -775,7 +775,7 @@ int do_potrf(hipStream_t st, const Ws& w) {
 }
 
 template <typename T>
-int do_potri(hipStream_t st, const Ws& w) {
+int do_trtri(hipStream_t st, const Ws& w) {
     T* M = (T*)(w.base + w.off_M);
     T* W = (T*)(w.base + w.off_W);
     T* V = (T*)(w.base + w.off_V);
@@ -791,8 +791,22 @@ int do_potri(hipStream_t st, const Ws& w) {
         rc = launch_gemm<T, OP_TRTRI_W>(st, g, pairs * mb * mb, w.q);
         if (rc) return rc;
     }
-    g.A = W; g.B = W; g.C = V; g.p0 = 0;
+    return 0;
+}
+
+template <typename T>
+int do_lauum(hipStream_t st, const Ws& w) {
+    GemmArgs g;
+    g.sA = g.sB = g.sC = w.mat; g.ldA = g.ldB = g.ldC = w.npad; g.nb = w.nb; g.p0 = g.p1 = 0;
+    g.A = (T*)(w.base + w.off_W); g.B = g.A; g.C = (T*)(w.base + w.off_V);
     return launch_gemm<T, OP_LAUUM>(st, g, w.ntile_lower, w.q);
+}
+
+template <typename T>
+int do_potri(hipStream_t st, const Ws& w) {
+    int rc = do_trtri<T>(st, w);
+    if (rc) return rc;
+    return do_lauum<T>(st, w);
 }
 
 template <typename T, int DD>
@@ -950,6 +964,22 @@ int lcgp_potri(void* stream, int dtype, int n, int d, int p, int q_local, void* 
     return dtype == LCGP_F64 ? do_potri<double>((hipStream_t)stream, w) : do_potri<float>((hipStream_t)stream, w);
 }
 
+int lcgp_trtri(void* stream, int dtype, int n, int d, int p, int q_local, void* workspace) {
+    int rc = check_common(dtype, n, d, p, q_local);
+    if (rc) return rc;
+    if (!workspace) return bad("NULL workspace");
+    Ws w = carve(dtype, n, d, p, q_local, workspace);
+    return dtype == LCGP_F64 ? do_trtri<double>((hipStream_t)stream, w) : do_trtri<float>((hipStream_t)stream, w);
+}
+
+int lcgp_lauum(void* stream, int dtype, int n, int d, int p, int q_local, void* workspace) {
+    int rc = check_common(dtype, n, d, p, q_local);
+    if (rc) return rc;
+    if (!workspace) return bad("NULL workspace");
+    Ws w = carve(dtype, n, d, p, q_local, workspace);
+    return dtype == LCGP_F64 ? do_lauum<double>((hipStream_t)stream, w) : do_lauum<float>((hipStream_t)stream, w);
+}
+
 int lcgp_fetch_matrix(void* stream, int dtype, int n, int d, int p, int q_local, const void* workspace, int which, int k,
                       void* out) {
     int rc = check_common(dtype, n, d, p, q_local);
@@ -967,6 +997,19 @@ int lcgp_fetch_matrix(void* stream, int dtype, int n, int d, int p, int q_local,
         hipLaunchKernelGGL((fetch_kernel<float>), grid, dim3(256), 0, st,
                            (const float*)(w.base + off) + (size_t)k * w.mat, w.npad, n, (float*)out);
     CHECK_LAUNCH("fetch_kernel");
+    return 0;
+}
+
+int lcgp_fetch_vector(void* stream, int dtype, int n, int d, int p, int q_local, const void* workspace, int which, int k,
+                      void* out) {
+    int rc = check_common(dtype, n, d, p, q_local);
+    if (rc) return rc;
+    if (!workspace || !out) return bad("NULL pointer");
+    if (which < 0 || which > 1 || k < 0 || k >= q_local) return bad("which/k out of range");
+    Ws w = carve(dtype, n, d, p, q_local, (void*)workspace);
+    const char* src = w.base + (which == 0 ? w.off_b : w.off_z) + (size_t)k * w.npad * w.esz;
+    hipError_t e = hipMemcpyAsync(out, src, (size_t)n * w.esz, hipMemcpyDeviceToDevice, (hipStream_t)stream);
+    if (e != hipSuccess) return fail("hipMemcpyAsync", e);
     return 0;
 }
 

@@ -1,0 +1,630 @@
+"""LCGP with the reference's Python surface, hot path on MI355X.
+
+Host-side mirror of `lcgp.LCGP` (reference `src/lcgp/lcgp.py:19-930`): same constructor, attributes, methods,
+exceptions and return shapes, so a caller of the reference can switch imports.  The one-off preprocessing
+(standardisation, replicate grouping, SVD basis, initial parameters; lcgp.py:295-513) is host numpy; what
+`fit()` loops over and what `predict()` consumes -- covariance build, factorisation, NLL, its gradient, the
+prediction caches -- runs in liblcgp_hip.so (include/lcgp_hip.h).  There is no CPU fallback for that part.
+
+Deliberate differences from the reference, all documented in DESIGN.md:
+  * gradients are closed-form instead of a TensorFlow tape; the Cholesky form of the objective
+    replaces the eigendecomposition (identical value);
+  * prediction caches are invalidated by `fit()`/parameter changes (the reference reuses stale ones);
+  * the (q,n,n) cache tensors `Ths`/`Tks` are materialised only when read, never at construction;
+  * results are CPU float64 torch tensors (the reference returns TF tensors; both have .numpy()/.shape);
+  * the unconditional "VARIANCE OF G" print (lcgp.py:482-483) happens only with verbose=True;
+  * keyword-only extras: device, dtype ('float64' | 'float32'), process_group (component-parallel multi-GPU).
+"""
+from __future__ import annotations
+
+import numpy as np
+import scipy.optimize as sopt
+import torch
+
+from . import dist as _dist
+from .params import Parameter, SoftClip
+
+F64 = np.float64
+
+
+def _t(a):
+    """numpy -> CPU float64 torch tensor (what the public surface hands out)."""
+    return torch.as_tensor(np.asarray(a, dtype=F64))
+
+
+def _np(a):
+    if isinstance(a, torch.Tensor):
+        return a.detach().cpu().numpy().astype(F64)
+    if isinstance(a, Parameter):
+        return a.numpy()
+    return np.asarray(a, dtype=F64)
+
+
+def _percentile50_nearest(a):
+    """tfp.stats.percentile(a, 50.0, axis=1, keepdims=True) with its default 'nearest' interpolation
+    (lcgp.py:317-318, 388-389): ascending sort, index round-half-even(0.5 (m-1)).  Not np.median."""
+    a = np.asarray(a, F64)
+    idx = int(np.round(0.5 * (a.shape[1] - 1)))
+    return np.sort(a, axis=1)[:, idx:idx + 1]
+
+
+class LCGP:
+    """
+    Latent Component Gaussian Process (LCGP), MI355X hot path.
+
+      - submethod='full': uses all observations (x, y)
+      - submethod='rep' : groups replicated x rows, uses (x_unique, ybar) structures
+    """
+
+    # =============================================================================================
+    # constructor (lcgp.py:31-222)
+    # =============================================================================================
+    def __init__(self, y=None, x=None, q=None, var_threshold=None, diag_error_structure=None,
+                 parameter_clamp_flag=False, robust_mean=True, submethod='full', rep_standardize_ybar=True,
+                 verbose=False, *, device=None, dtype='float64', process_group=None):
+        self.verbose = verbose
+        self.robust_mean = robust_mean
+        self.rep_standardize_ybar = rep_standardize_ybar
+        self.parameter_clamp_flag = parameter_clamp_flag
+        self._device = device
+        self._dtype = dtype
+        self._group = process_group
+        self._engine = None
+        self._aux_valid = False
+        self._aux_override = {}
+
+        self.x = self._verify_data_types(x)
+        self.y = self._verify_data_types(y)
+
+        self.method = 'LCGP'
+        if submethod not in ['full', 'rep']:
+            raise ValueError('Invalid submethod. Choices are \'full\' or \'rep\'.')
+        self.submethod = submethod
+        self.submethod_loss_map = {'full': self.neglpost, 'rep': self.neglpost_rep}
+        self.submethod_predict_map = {'full': self.predict_full, 'rep': self.predict_rep}
+
+        if (q is not None) and (var_threshold is not None):
+            raise ValueError('Include only q or var_threshold but not both.')
+        self.q = q
+        self.var_threshold = var_threshold
+
+        self.n, self.d, self.p = self.verify_dim(self.y, self.x)
+        self.x_orig = self.x
+        self.y_orig = self.y
+
+        self.x, self.x_min, self.x_max, _, self.xnorm = self.init_standard_x(self.x)
+
+        self._rep_initialized = False
+        if self.submethod == 'rep':
+            (self.x_unique, self.x_unique_s, self.group_ids, self.r, self.R, self.ybar, self.ybar_s,
+             self.ybar_mean, self.ybar_std, self.n, self.d, self.p) = self.preprocess()
+            self._rep_initialized = True
+        else:
+            self.y, self.ymean, self.ystd, _ = self.init_standard_y(self.y)
+
+        self.g, self.phi, self.diag_D, self.q = self.init_phi(var_threshold=var_threshold)
+
+        if diag_error_structure is None:
+            self.diag_error_structure = [1] * int(self.p)
+        else:
+            self.diag_error_structure = diag_error_structure
+        self.verify_error_structure(self.diag_error_structure, self.y)
+
+        d_in = self.x.shape[1]
+        self.lLmb = Parameter(np.ones((self.q, d_in)), 'Latent GP log-scale', SoftClip(1e-6, 1e4))
+        self.lLmb0 = Parameter(np.ones(self.q), 'Latent GP log-lengthscale', SoftClip(1e-4, 1e4))
+        self.lsigma2s = Parameter(np.ones(len(self.diag_error_structure)), 'Diagonal error log-variance')
+        self.lnugGPs = Parameter(np.ones(self.q) * 1e-6, 'Latent GP nugget scale',
+                                 SoftClip(np.exp(-16.0), np.exp(-2.0)))
+        self.init_params()
+        self.ghat = None
+        self.gvar = None
+        self.psi_c = None
+
+    # =============================================================================================
+    # display (lcgp.py:227-243)
+    # =============================================================================================
+    def __repr__(self):
+        rows = []
+        for par in (self.lLmb, self.lLmb0, self.lsigma2s, self.lnugGPs):
+            tr = type(par.transform).__name__
+            rows.append('\t\t%-32s %-9s shape=%-10s value=%s' % (
+                par.name, tr, str(tuple(par.shape)), np.array2string(par.numpy(), precision=5, threshold=8)))
+        return ('LCGP(\n'
+                '\tsubmethod:\t{:s}\n'
+                '\toutput dimension:\t{:d}\n'
+                '\tnumber of latent components:\t{:d}\n'
+                '\tparameter_clamping:\t{:s}\n'
+                '\trobust_standardization:\t{:s}\n'
+                '\tdiagonal_error structure:\t{:s}\n'
+                '\tparameters:\t\n{}\n)').format(self.submethod, int(self.p), int(self.q),
+                                                 str(self.parameter_clamp_flag), str(self.robust_mean),
+                                                 str(self.diag_error_structure), '\n'.join(rows))
+
+    # =============================================================================================
+    # validation / transforms (lcgp.py:248-290)
+    # =============================================================================================
+    @staticmethod
+    def _verify_data_types(t):
+        if isinstance(t, torch.Tensor):
+            t = t.detach().to('cpu', torch.float64)
+        else:
+            t = torch.as_tensor(np.asarray(t, dtype=F64))
+        if t.ndim < 2:
+            t = t.unsqueeze(1)
+        return t
+
+    def verify_dim(self, y, x):
+        p, ny = y.shape[0], y.shape[1]
+        nx, d = x.shape[0], x.shape[1]
+        assert ny == nx, 'Number of inputs (x) differs from number of outputs (y), y.shape[1] != x.shape[0]'
+        return (torch.tensor(nx, dtype=torch.int32), torch.tensor(d, dtype=torch.int32),
+                torch.tensor(p, dtype=torch.int32))
+
+    @staticmethod
+    def verify_error_structure(diag_error_structure, y):
+        assert sum(diag_error_structure) == y.shape[0], \
+            'Sum of error_structure should equal the output dimension.'
+
+    def tx_x(self, xs):
+        return _t(_np(xs) * (_np(self.x_max) - _np(self.x_min)) + _np(self.x_min))
+
+    def tx_y(self, ys):
+        return _t(_np(ys) * _np(self.ystd) + _np(self.ymean))
+
+    # =============================================================================================
+    # standardisation (lcgp.py:295-324)
+    # =============================================================================================
+    @staticmethod
+    def init_standard_x(x):
+        xn = _np(x)
+        x_max = xn.max(axis=0)
+        x_min = xn.min(axis=0)
+        xs = (xn - x_min) / (x_max - x_min)
+        # mean of the strictly positive |x_i - x_i'| over ordered pairs (lcgp.py:304-309), from a sort:
+        # sum_{i,i'} |x_i - x_i'| = 2 sum_k (2k - n + 1) x_(k);  #positive pairs = n^2 - sum_v count_v^2
+        n = xn.shape[0]
+        xnorm = np.zeros(xn.shape[1], F64)
+        coef = 2.0 * np.arange(n) - n + 1.0
+        for j in range(xn.shape[1]):
+            s = np.sort(xn[:, j])
+            _, cnt = np.unique(s, return_counts=True)
+            npos = float(n) * n - float(np.sum(cnt.astype(F64) ** 2))
+            xnorm[j] = 2.0 * float(coef @ s) / npos if npos > 0 else np.nan
+        return _t(xs), _t(x_min), _t(x_max), x, _t(xnorm)
+
+    def init_standard_y(self, y):
+        yn = _np(y)
+        if self.robust_mean:
+            ycenter = _percentile50_nearest(yn)
+            yspread = _percentile50_nearest(np.abs(yn - ycenter))
+        else:
+            ycenter = yn.mean(axis=1, keepdims=True)
+            yspread = yn.std(axis=1, keepdims=True)
+        ys = (yn - ycenter) / yspread
+        return _t(ys), _t(ycenter), _t(yspread), y
+
+    # =============================================================================================
+    # replication preprocessing (lcgp.py:329-434)
+    # =============================================================================================
+    def _get_raw_xy(self, x_raw=None, y_raw=None):
+        xr = _np(self.x_orig if x_raw is None else x_raw)
+        yr = _np(self.y_orig if y_raw is None else y_raw)
+        assert xr.ndim == 2, "x_raw must be (N, d)"
+        assert yr.ndim == 2, "y_raw must be (p, N)"
+        N, d = xr.shape
+        p, Ny = yr.shape
+        assert Ny == N, "y_raw columns must match x_raw rows"
+        return xr, yr, N, d, p
+
+    def _group_unique_rows_np(self, xr):
+        x_unique, inverse, counts = np.unique(xr, axis=0, return_inverse=True, return_counts=True)
+        return x_unique, np.asarray(inverse).reshape(-1), counts
+
+    def _compute_ybar_np(self, yr, inverse, n):
+        p, N = yr.shape
+        sums = np.zeros((p, n), F64)
+        np.add.at(sums.T, inverse, yr.T)
+        return sums / np.bincount(inverse, minlength=n).astype(F64)[None, :]
+
+    def _pack_replication_tensors(self, x_unique_np, inverse_np, r_np, ybar_np):
+        x_unique_s = (x_unique_np - _np(self.x_min)) / (_np(self.x_max) - _np(self.x_min))
+        r_t = torch.as_tensor(np.asarray(r_np, np.int32))
+        return (_t(x_unique_np), _t(x_unique_s), torch.as_tensor(np.asarray(inverse_np, np.int32)), r_t,
+                torch.diag(r_t.to(torch.float64)), _t(ybar_np))
+
+    def _compute_center_spread_tf(self, Y):
+        """(center, spread) per output row; non-positive spread -> 1 (lcgp.py:383-395).  Name kept for
+        drop-in compatibility; nothing here is TensorFlow."""
+        yn = _np(Y)
+        if self.robust_mean:
+            c = _percentile50_nearest(yn)
+            s = _percentile50_nearest(np.abs(yn - c))
+        else:
+            c = yn.mean(axis=1, keepdims=True)
+            s = yn.std(axis=1, keepdims=True)
+        s = np.where(s > 0, s, 1.0)
+        return _t(c), _t(s)
+
+    def preprocess(self, y_raw=None, x_raw=None):
+        """12-tuple of replication structures (lcgp.py:397-426)."""
+        xr, yr, N, d, p = self._get_raw_xy(x_raw=x_raw, y_raw=y_raw)
+        x_unique_np, inverse_np, counts_np = self._group_unique_rows_np(xr)
+        n_unique = int(x_unique_np.shape[0])
+        r_np = counts_np.astype(np.int32)
+        ybar_np = self._compute_ybar_np(yr, inverse_np, n_unique)
+        x_unique, x_unique_s, group_ids, r_t, R_t, ybar = self._pack_replication_tensors(
+            x_unique_np, inverse_np, r_np, ybar_np)
+        ybar_mean, ybar_std = self._compute_center_spread_tf(ybar)
+        ybar_s = (ybar - ybar_mean) / ybar_std
+        return (x_unique, x_unique_s, group_ids, r_t, R_t, ybar, ybar_s, ybar_mean, ybar_std,
+                torch.tensor(n_unique, dtype=torch.int32), torch.tensor(d, dtype=torch.int32),
+                torch.tensor(p, dtype=torch.int32))
+
+    def _ensure_replication(self):
+        if not self._rep_initialized:
+            self.preprocess()
+            self._rep_initialized = True
+
+    # =============================================================================================
+    # basis (lcgp.py:439-485)
+    # =============================================================================================
+    def _get_phi_input(self):
+        if self.submethod != "rep":
+            return self.y
+        if getattr(self, "rep_standardize_ybar", True) and hasattr(self, "ybar_s"):
+            return self.ybar_s
+        if hasattr(self, "ybar"):
+            return self.ybar
+        return self.y
+
+    def init_phi(self, var_threshold=None):
+        y = _np(self._get_phi_input())
+        n = int(self.n)
+        p = int(self.p)
+        left_u, singvals, _ = np.linalg.svd(y, full_matrices=False)
+        if (self.q is None) and (var_threshold is None):
+            q = p
+        elif (self.q is None) and (var_threshold is not None):
+            cumvar = np.cumsum(singvals ** 2) / np.sum(singvals ** 2)
+            q = int(np.argmax(cumvar > var_threshold) + 1) if np.any(cumvar > var_threshold) else p
+        else:
+            q = int(self.q)
+        assert left_u.shape[1] == min(n, p)
+        phi = left_u[:, :q] * np.sqrt(float(n)) / singvals[:q]
+        diag_D = np.sum(phi ** 2, axis=0)
+        g = phi.T @ y
+        if self.verbose:
+            print("======= VARIANCE OF G ======")
+            print(np.var(g, axis=1))
+        return _t(g), _t(phi), _t(diag_D), q
+
+    # =============================================================================================
+    # parameters (lcgp.py:490-532)
+    # =============================================================================================
+    def init_params(self):
+        x = _np(self.x)
+        d = int(self.d)
+        llmb = np.exp(0.5 * np.log(d) + np.log(np.std(x, axis=0)))
+        y = _np(self.y)
+        err_struct = self.diag_error_structure
+        lsigma2_diag = np.zeros(len(err_struct), F64)
+        col = 0
+        for k in range(len(err_struct)):
+            lsigma2_diag[k] = np.log(np.var(y[col:(col + err_struct[k])]))
+            col += err_struct[k]
+        self.lLmb.assign(np.tile(llmb, self.q).reshape((self.q, d)))
+        self.lLmb0.assign(np.ones(self.q, F64))
+        self.lnugGPs.assign(np.exp(-10.) * np.ones(self.q, F64))
+        self.lsigma2s.assign(lsigma2_diag)
+        self._invalidate()
+
+    def get_param(self):
+        """(lLmb (q,d), lLmb0 (q,), built_lsigma2s (p,), lnugGPs (q,)) -- constrained values."""
+        built = np.repeat(self.lsigma2s.numpy(), np.asarray(self.diag_error_structure, int))
+        return _t(self.lLmb.numpy()), _t(self.lLmb0.numpy()), _t(built), _t(self.lnugGPs.numpy())
+
+    @property
+    def trainable_variables(self):
+        # tf.Module order: attribute names sorted -> lLmb, lLmb0, lnugGPs, lsigma2s
+        return tuple(par.variable() for par in (self.lLmb, self.lLmb0, self.lnugGPs, self.lsigma2s))
+
+    def _get_flat(self):
+        return np.concatenate([self.lLmb.unconstrained.reshape(-1), self.lLmb0.unconstrained,
+                               self.lnugGPs.unconstrained, self.lsigma2s.unconstrained])
+
+    def _set_flat(self, u):
+        u = np.asarray(u, F64)
+        q, d, ns = self.q, int(self.d), len(self.diag_error_structure)
+        a = q * d
+        self.lLmb.unconstrained = u[:a].reshape(q, d).copy()
+        self.lLmb0.unconstrained = u[a:a + q].copy()
+        self.lnugGPs.unconstrained = u[a + q:a + 2 * q].copy()
+        self.lsigma2s.unconstrained = u[a + 2 * q:a + 2 * q + ns].copy()
+        self._invalidate()
+
+    def _invalidate(self):
+        self._aux_valid = False
+        self._aux_override = {}
+
+    # =============================================================================================
+    # the hot path (lcgp.py:537-666 + the gpflow/TF gradient tape)
+    # =============================================================================================
+    def _make_engine(self):
+        """One rank's share of the path on the GPU (raises without a GPU: no CPU fallback)."""
+        from .engine import HotPathEngine
+        rank, world = _dist.rank_world(self._group)
+        self._local_ks = _dist.local_components(self.q, rank, world)
+        if not self._local_ks:
+            return None
+        if self.submethod == 'rep':
+            sr = np.sqrt(_np(self.r))
+            ybar_used = _np(self.ybar_s if self.rep_standardize_ybar else self.ybar)
+            return HotPathEngine(_np(self.x_unique_s), ybar_used * sr[None, :], sr, len(self._local_ks),
+                                 self._dtype, self._device)
+        return HotPathEngine(_np(self.x), _np(self.y), None, len(self._local_ks), self._dtype, self._device)
+
+    def _get_engine(self):
+        if self._engine is None:
+            self._engine = self._make_engine()
+            self._path_consts()
+        return self._engine
+
+    def _path_consts(self):
+        """Parameter-independent pieces of the objective."""
+        rank, world = _dist.rank_world(self._group)
+        self._local_ks = _dist.local_components(self.q, rank, world)
+        if self.submethod == 'rep':
+            r = _np(self.r)
+            ybar_used = _np(self.ybar_s if self.rep_standardize_ybar else self.ybar)
+            yeff = ybar_used * np.sqrt(r)[None, :]
+            self._ysq = np.sum(yeff * yeff, axis=1)
+            self._std = _np(self.ybar_std)[:, 0] if self.rep_standardize_ybar else np.ones(int(self.p), F64)
+            self._sum_log_r = float(np.sum(np.log(r)))
+        else:
+            yn = _np(self.y)
+            self._ysq = np.sum(yn * yn, axis=1)
+            self._std = np.ones(int(self.p), F64)
+            self._sum_log_r = 0.0
+
+    def _theta_rows(self, sig_eff):
+        lLmb, lLmb0, lnug = self.lLmb.numpy(), self.lLmb0.numpy(), self.lnugGPs.numpy()
+        phi, D = _np(self.phi), _np(self.diag_D)
+        rows = [np.concatenate([lLmb[k], [lLmb0[k], lnug[k], D[k]], phi[:, k] / sig_eff]) for k in self._local_ks]
+        return np.asarray(rows, F64).reshape(len(self._local_ks), int(self.d) + 3 + int(self.p))
+
+    def _run_path(self):
+        """One evaluation at the current parameters: returns (value, gradient w.r.t. the CONSTRAINED
+        parameters in flat order lLmb, lLmb0, lnugGPs, lsigma2s).  Rep values already carry the 1/n."""
+        eng = self._get_engine()
+        self._u_last = self._get_flat().copy()
+        n, d, p, q = int(self.n), int(self.d), int(self.p), int(self.q)
+        es = np.asarray(self.diag_error_structure, int)
+        ls2_b = np.repeat(self.lsigma2s.numpy(), es)
+        sig_eff = np.exp(0.5 * ls2_b) / self._std
+        phi, D = _np(self.phi), _np(self.diag_D)
+        # partial (P_b + 2)-vector of this rank: [nll, info, g_lLmb (q d), g_lLmb0 (q), g_lnug (q), g_ls2_built (p)]
+        vec = np.zeros(2 + q * d + 2 * q + p, F64)
+        if eng is not None:
+            out = eng.evaluate(self._theta_rows(sig_eff))
+            for row, k in zip(out, self._local_ks):
+                vec[0] += row[0] - row[1] / (2.0 * D[k])
+                vec[1] += row[2]
+                vec[2 + k * d:2 + (k + 1) * d] = row[3:3 + d]
+                vec[2 + q * d + k] = row[3 + d]
+                vec[2 + q * d + q + k] = row[4 + d]
+                vec[2 + q * d + 2 * q:] += 0.5 / sig_eff * phi[:, k] * row[5 + d:5 + d + p] / D[k]
+        vec = _dist.all_reduce_sum(vec, self._group, None if eng is None else eng.device)
+        if vec[1] != 0 or not np.isfinite(vec[0]):
+            raise np.linalg.LinAlgError(
+                'I + D_k C_k is not numerically positive definite at the current parameters (info=%g)' % vec[1])
+        nll = vec[0] + 0.5 * np.sum(self._ysq / sig_eff ** 2) + n / 2.0 * np.sum(ls2_b - 2.0 * np.log(self._std)) \
+            - 0.5 * p * self._sum_log_r
+        g_b = vec[2 + q * d + 2 * q:] + n / 2.0 - 0.5 * self._ysq / sig_eff ** 2
+        g_ls2 = np.add.reduceat(g_b, np.r_[0, np.cumsum(es)[:-1]])
+        grad = np.concatenate([vec[2:2 + q * d + 2 * q], g_ls2])
+        if self.submethod == 'rep':
+            return float(nll / n), grad / n
+        return float(nll), grad
+
+    def loss_and_grad(self, u=None):
+        """NLL and d NLL / d unconstrained flat vector (what gpflow's Scipy wrapper hands L-BFGS-B)."""
+        if u is not None:
+            self._set_flat(u)
+        val, g = self._run_path()
+        jac = np.concatenate([self.lLmb.transform.dforward(self.lLmb.unconstrained).reshape(-1),
+                              self.lLmb0.transform.dforward(self.lLmb0.unconstrained),
+                              self.lnugGPs.transform.dforward(self.lnugGPs.unconstrained),
+                              np.ones(self.lsigma2s.size, F64)])
+        self._aux_valid = True   # the workspace now holds L, L^-1, A^-1, z at the current parameters
+        return val, g * jac
+
+    def fit(self, verbose=False):
+        """scipy L-BFGS-B with default options on the unconstrained vector (lcgp.py:537-540)."""
+        if self.submethod not in self.submethod_loss_map:
+            raise ValueError("Invalid submethod. Choices are 'full' or 'rep'.")
+        u0 = self._get_flat()
+        res = sopt.minimize(lambda u: self.loss_and_grad(u), u0, jac=True, method='L-BFGS-B')
+        self._set_flat(res.x)
+        self.opt_result = res
+        return
+
+    def loss(self):
+        try:
+            return self.submethod_loss_map[self.submethod]()
+        except KeyError:
+            raise ValueError("Invalid submethod. Choices are 'full' or 'rep'.")
+
+    def neglpost(self):
+        """lcgp.py:635-666 (value only; a 0-d float64 tensor)."""
+        self._require_mode('full')
+        val, _ = self._run_path()
+        self._aux_valid = True
+        return torch.tensor(val, dtype=torch.float64)
+
+    def neglpost_rep(self):
+        """lcgp.py:554-630."""
+        self._require_mode('rep')
+        val, _ = self._run_path()
+        self._aux_valid = True
+        return torch.tensor(val, dtype=torch.float64)
+
+    def _require_mode(self, mode):
+        built = 'rep' if hasattr(self, 'x_unique') and hasattr(self, 'ybar') else 'full'
+        if mode != built:
+            raise ValueError('model was preprocessed for submethod=%r' % built)
+
+    # =============================================================================================
+    # prediction (lcgp.py:671-930)
+    # =============================================================================================
+    def predict(self, x0, return_fullcov=False):
+        x0 = self._verify_data_types(x0)
+        try:
+            predict_call = self.submethod_predict_map[self.submethod]
+        except KeyError as e:
+            print(e)
+            raise KeyError('Invalid submethod.  Choices are \'full\' or \'rep\'.')
+        result = predict_call(x0=x0, return_fullcov=return_fullcov)
+        return tuple(r.detach() if r is not None else None for r in result)
+
+    def compute_aux_predictive_quantities(self):
+        """Factorise at the current parameters so that predict() can reuse L^-1, A^-1 and z (replaces the
+        eigendecomposition caches of lcgp.py:685-726 / the Cholesky caches of 728-803)."""
+        if hasattr(self, 'x_unique') and hasattr(self, 'ybar'):
+            self._compute_aux_predictive_quantities_rep()
+            return
+        self._run_path()
+        self._aux_valid = True
+        self._aux_override = {}
+
+    def _compute_aux_predictive_quantities_rep(self):
+        self._run_path()
+        self._aux_valid = True
+        self._aux_override = {}
+        ls2_b = _np(self.get_param()[2])
+        sis = np.exp(-0.5 * ls2_b) * self._std
+        phi = _np(self.phi)
+        # the reference writes phi^T / sigma_inv_sqrt_used[:, None] (lcgp.py:754), which broadcasts only
+        # when q == p (or 1); keep that expression there and fall back to the per-output scaling otherwise
+        try:
+            self.psi_c = _t(phi.T / sis[:, None])
+        except ValueError:
+            self.psi_c = _t(phi.T / sis[None, :])
+
+    def _ensure_aux(self):
+        eng = self._get_engine()
+        # rank-independent test (all ranks must enter the collective together): is the factorisation in the
+        # workspace the one of the current parameter vector?
+        stale = getattr(self, '_u_last', None) is None or not np.array_equal(self._u_last, self._get_flat())
+        if (not self._aux_valid) or self._aux_override or stale:
+            self.compute_aux_predictive_quantities()
+        return eng
+
+    def _latent_predict(self, x0):
+        """ghat, gvar (q, n0) for raw-scale x0 (lcgp.py:822-838 / 877-900)."""
+        eng = self._ensure_aux()
+        x0n = _np(x0)
+        x0s = (x0n - _np(self.x_min)) / (_np(self.x_max) - _np(self.x_min))
+        xtrain = _np(self.x_unique_s if self.submethod == 'rep' else self.x)
+        # the nugget is added iff x0 and the training inputs agree in shape and value (covmat.py:46-51)
+        same = (x0s.shape == xtrain.shape) and bool(np.all(x0s == xtrain))
+        n0 = x0s.shape[0]
+        if eng is not None:
+            gh, gv = eng.predict(x0s, same)
+        else:
+            gh = gv = np.zeros((0, n0))
+        dev = None if eng is None else eng.device
+        ghat = _dist.gather_rows(gh, int(self.q), self._group, dev)
+        gvar = _dist.gather_rows(gv, int(self.q), self._group, dev)
+        self.ghat, self.gvar = _t(ghat), _t(gvar)
+        return ghat, gvar
+
+    def predict_full(self, x0, return_fullcov=False):
+        """lcgp.py:808-859."""
+        ghat, gvar = self._latent_predict(x0)
+        ls2_b = _np(self.get_param()[2])
+        phi = _np(self.phi)
+        ystd, ymean = _np(self.ystd), _np(self.ymean)
+        psi = phi.T * np.sqrt(np.exp(ls2_b))
+        predmean = psi.T @ ghat
+        confvar = gvar.T @ psi ** 2
+        predvar = confvar + np.exp(ls2_b)
+        ypred = predmean * ystd + ymean
+        yconfvar = confvar.T * ystd ** 2
+        ypredvar = predvar.T * ystd ** 2
+        if return_fullcov:
+            ch = np.einsum('kn,kp->npk', np.sqrt(gvar), psi)
+            cov = ch @ np.transpose(ch, (0, 2, 1)) + np.diag(np.exp(ls2_b))[None, ...]
+            sv = ystd[:, 0]
+            cov = cov * (sv[:, None] * sv[None, :])[None, ...]
+            return _t(ypred), _t(ypredvar), _t(yconfvar), _t(cov)
+        return _t(ypred), _t(ypredvar), _t(yconfvar)
+
+    def predict_rep(self, x0, return_fullcov=False):
+        """lcgp.py:864-930."""
+        ghat, gvar = self._latent_predict(x0)
+        ls2_b = _np(self.get_param()[2])
+        phi = _np(self.phi)
+        use_std = getattr(self, "rep_standardize_ybar", True)
+        std = _np(self.ybar_std)[:, 0] if use_std else np.ones(int(self.p), F64)
+        s_sqrt = np.sqrt(np.exp(ls2_b)) / std
+        s_var = np.exp(ls2_b) / std ** 2
+        Psi = phi * s_sqrt[:, None]
+        pm = Psi @ ghat
+        cv = (Psi ** 2) @ gvar
+        pv = cv + s_var[:, None]
+        if use_std:
+            ybs, ybm = _np(self.ybar_std), _np(self.ybar_mean)
+            ypred, yconfvar, ypredvar = pm * ybs + ybm, cv * ybs ** 2, pv * ybs ** 2
+        else:
+            ypred, yconfvar, ypredvar = pm, cv, pv
+        if return_fullcov:
+            return _t(ypred), _t(ypredvar), _t(yconfvar), None
+        return _t(ypred), _t(ypredvar), _t(yconfvar)
+
+    # ---- cache views the reference keeps as attributes (materialised from the device only when read) ----
+    def _fetch_all(self, fn, width):
+        eng = self._engine
+        rows = np.zeros((len(self._local_ks), width), F64)
+        for i in range(len(self._local_ks)):
+            rows[i] = fn(eng, i).reshape(-1)
+        return _dist.gather_rows(rows, int(self.q), self._group, None if eng is None else eng.device)
+
+    def _cache_get(self, name):
+        if name in self._aux_override:
+            return self._aux_override[name]
+        if not self._aux_valid or self._engine is None:
+            n = int(self.n)
+            if name in ('CinvMs', 'mks'):
+                return torch.full((int(self.q), n), float('nan'), dtype=torch.float64)
+            return None
+        n = int(self.n)
+        sr = np.sqrt(_np(self.r)) if self.submethod == 'rep' else np.ones(n, F64)
+        D = _np(self.diag_D)
+        if name == 'CinvMs':      # (I + D_k C_k)^-1 B_k (full, lcgp.py:708);  b_k - D_k R m_k = sqrt(r) o z_k (rep, 781)
+            return _t(self._fetch_all(lambda e, i: e.fetch_vector(1, i), n) * sr[None, :])
+        if name == 'mks':         # (C_k^-1 + D_k R)^-1 b_k = (beta - z) / (D_k sqrt(r))      (lcgp.py:779)
+            b = self._fetch_all(lambda e, i: e.fetch_vector(0, i), n)
+            z = self._fetch_all(lambda e, i: e.fetch_vector(1, i), n)
+            return _t((b - z) / (D[:, None] * sr[None, :]))
+        if name == 'Tks':         # C^-1 - C^-1 (C^-1 + D R)^-1 C^-1 = D R^1/2 A^-1 R^1/2      (lcgp.py:783-788)
+            if self.submethod != 'rep':
+                return None
+            ainv = self._fetch_all(lambda e, i: e.fetch_matrix(2, i), n * n).reshape(int(self.q), n, n)
+            return _t(D[:, None, None] * ainv * sr[None, :, None] * sr[None, None, :])
+        if name == 'Ths':         # Th_k Th_k^T = D_k A_k^-1 (lcgp.py:709-715); returned as the Cholesky-type factor
+            if self.submethod != 'full':
+                return None
+            w = self._fetch_all(lambda e, i: e.fetch_matrix(1, i), n * n).reshape(int(self.q), n, n)
+            w = np.tril(w)
+            return _t(np.sqrt(D)[:, None, None] * np.transpose(w, (0, 2, 1)))
+        raise AttributeError(name)
+
+    def _cache_set(self, name, value):
+        self._aux_override[name] = value
+        self._aux_valid = False
+
+    CinvMs = property(lambda self: self._cache_get('CinvMs'), lambda self, v: self._cache_set('CinvMs', v))
+    mks = property(lambda self: self._cache_get('mks'), lambda self, v: self._cache_set('mks', v))
+    Tks = property(lambda self: self._cache_get('Tks'), lambda self, v: self._cache_set('Tks', v))
+    Ths = property(lambda self: self._cache_get('Ths'), lambda self, v: self._cache_set('Ths', v))

@@ -429,6 +429,9 @@ class OracleLCGP:
         self.lLmb, self.lLmb0, self.lnugGPs, self.lsigma2s = init_param_values(
             self.x, self.y, self.d, self.q, self.diag_error_structure)
         self._aux = None
+        # gpflow.Parameter.assign stores the UNCONSTRAINED value and re-applies the bijector on every read
+        # (lcgp.py:509-512): the constrained values carry that round trip (~1e-12 for bounds of 1e4)
+        self.set_unconstrained(self.get_unconstrained())
 
     # --- parameter vector seen by L-BFGS-B ------------------------------------------------
     def _sizes(self):

@@ -1,0 +1,66 @@
+"""Worker of tests/test_dist_gloo.py: one rank of a world_size-2 gloo job (CPU).  The hot path itself is
+answered by the test-only OracleEngine; what is under test is the component sharding (k -> rank k mod G), the
+single all-reduce of the (P+1)-vector, the lock-step L-BFGS-B and the gather in predict()."""
+import os
+import sys
+
+import numpy as np
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from lcgp_amd import LCGP, synth  # noqa: E402
+from lcgp_amd import dist as ldist  # noqa: E402
+from oracle import lcgp_oracle as orc  # noqa: E402
+from tests.helpers import patch_engine  # noqa: E402
+
+
+def main():
+    dist.init_process_group("gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    assert world == 2
+    assert ldist.local_components(5, rank, world) == ([0, 2, 4] if rank == 0 else [1, 3])
+    for mode, q in (("full", 3), ("rep", 4)):
+        if mode == "full":
+            x, y = synth.make_full(21, 40, 2, 4, 3)
+        else:
+            x, y = synth.make_rep(22, 15, 3, 2, 4, 4)
+        m = patch_engine(LCGP(y=y, x=x, q=q, submethod=mode))
+        o = orc.OracleLCGP(y=y, x=x, q=q, submethod=mode)
+        o.phi = m.phi.numpy().copy()
+        for u in synth.param_points(21, o.get_unconstrained()):
+            v1, g1 = m.loss_and_grad(u)
+            v2, g2 = o.loss_and_grad_unconstrained(u)
+            assert len(m._local_ks) == len(ldist.local_components(q, rank, world))
+            assert abs(v1 - v2) <= 1e-12 * max(1.0, abs(v2)), (rank, v1, v2)
+            np.testing.assert_allclose(g1, g2, rtol=1e-10, atol=1e-12 * np.max(np.abs(g2)))
+        m.fit()
+        # lock-step: both ranks must hold bit-identical parameters without any broadcast
+        flat = m._get_flat()
+        both = [None, None]
+        dist.all_gather_object(both, flat.tobytes())
+        assert both[0] == both[1]
+        o.set_unconstrained(flat)
+        x0 = np.random.default_rng(5).uniform(0, 1, (7, 2))
+        got = m.predict(x0)
+        want = o.predict(x0)
+        for a, b in zip(got, want):
+            np.testing.assert_allclose(a.numpy(), b, rtol=1e-7, atol=1e-9)
+    # q < world: rank 1 holds no component and still takes part in the collectives
+    x, y = synth.make_full(23, 30, 2, 3, 1)
+    m = patch_engine(LCGP(y=y, x=x, q=1))
+    o = orc.OracleLCGP(y=y, x=x, q=1)
+    o.phi = m.phi.numpy().copy()
+    v1, g1 = m.loss_and_grad(o.get_unconstrained())
+    v2, g2 = o.loss_and_grad_unconstrained(o.get_unconstrained())
+    assert abs(v1 - v2) <= 1e-12 * abs(v2)
+    np.testing.assert_allclose(g1, g2, rtol=1e-10, atol=1e-13)
+    np.testing.assert_allclose(m.predict(x[:5])[0].numpy(), o.predict(x[:5])[0], rtol=1e-7, atol=1e-9)
+    dist.barrier()
+    dist.destroy_process_group()
+    print("RANK %d OK" % rank)
+
+
+if __name__ == "__main__":
+    main()

@@ -348,10 +348,10 @@ static void run_case(int n, int d, int p, int q, bool rep, unsigned seed) {
                 }
         }
         report("matern32 rectangular", relmax(mg, mr), sizeof(T) == 8 ? 1e-14 : 1e-6);
-        hipFree(dx0); hipFree(dscr); hipFree(dgh); hipFree(dgv);
+        (void)hipFree(dx0); (void)hipFree(dscr); (void)hipFree(dgh); (void)hipFree(dgv);
     }
-    hipFree(ws); hipFree(dx); hipFree(dY); hipFree(dsr); hipFree(dmat); hipFree(dtheta); hipFree(dout);
-    hipFree(dld); hipFree(dinfo);
+    (void)hipFree(ws); (void)hipFree(dx); (void)hipFree(dY); (void)hipFree(dsr); (void)hipFree(dmat); (void)hipFree(dtheta); (void)hipFree(dout);
+    (void)hipFree(dld); (void)hipFree(dinfo);
 }
 
 int main(int argc, char** argv) {

@@ -1,0 +1,243 @@
+"""Parity of the HIP hot path (through the C ABI, liblcgp_hip.so) against the CPU oracle, the committed golden
+vectors and the reference's stored notebook numbers.  Tolerances are BASELINE.json's: NLL 1e-6 relative,
+gradient 1e-5 relative to max|g| (fp64).  Everything here needs a real MI355X."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from lcgp_amd import LCGP, Matern32, synth
+from oracle import lcgp_oracle as orc
+from tests import kat_data as kd
+
+pytestmark = pytest.mark.gpu
+
+NLL_RTOL = 1e-6
+GRAD_RTOL = 1e-5
+GOLD = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'lcgp_golden.npz'))
+
+
+def _check(m, o, pts):
+    o.phi = m.phi.numpy().copy()      # SVD sign freedom: compare at one basis
+    for u in pts:
+        v1, g1 = m.loss_and_grad(u)
+        v2, g2 = o.loss_and_grad_unconstrained(u)
+        assert abs(v1 - v2) <= NLL_RTOL * abs(v2), (v1, v2)
+        assert np.max(np.abs(g1 - g2)) <= GRAD_RTOL * np.max(np.abs(g2)), np.max(np.abs(g1 - g2))
+
+
+def test_native_library_is_the_one_running():
+    from lcgp_amd import _hip
+    lib = _hip.load()
+    assert lib.lcgp_version() >= 100
+    maps = open('/proc/self/maps').read()
+    assert 'liblcgp_hip.so' in maps
+
+
+@pytest.mark.parametrize('n,d,p,q,kw', [
+    (40, 1, 3, 3, {}),                                          # one tile, padded
+    (64, 2, 4, 3, {}),                                          # exactly one tile
+    (65, 2, 4, 2, dict(robust_mean=False)),                     # ragged: 1 row in the second tile
+    (200, 3, 6, 4, dict(diag_error_structure=[1, 2, 3])),
+    (333, 6, 5, 5, {}),
+    (512, 10, 8, 2, {}),
+])
+def test_full_path_matches_oracle(n, d, p, q, kw):
+    x, y = synth.make_full(100 + n, n, d, p, q)
+    m = LCGP(y=y, x=x, q=q, **kw)
+    o = orc.OracleLCGP(y=y, x=x, q=q, **kw)
+    _check(m, o, synth.param_points(n, o.get_unconstrained()))
+    assert abs(float(m.loss()) - o.loss()) <= NLL_RTOL * abs(o.loss())
+
+
+@pytest.mark.parametrize('nu,reps,d,p,kw', [
+    (20, 3, 2, 4, {}),
+    (70, 3, 2, 4, dict(rep_standardize_ybar=False)),
+    (130, 4, 3, 5, dict(q=3)),
+])
+def test_rep_path_matches_oracle(nu, reps, d, p, kw):
+    x, y = synth.make_rep(200 + nu, nu, reps, d, p, p)
+    m = LCGP(y=y, x=x, submethod='rep', **kw)
+    o = orc.OracleLCGP(y=y, x=x, submethod='rep', **kw)
+    _check(m, o, synth.param_points(nu, o.get_unconstrained()))
+    assert abs(float(m.loss()) - o.loss_reference_form()) <= NLL_RTOL * abs(o.loss())
+
+
+def test_uneven_replication_counts_kat_data():
+    xtr, ytr, _, _ = kd.kat_dataset()
+    m = LCGP(y=ytr, x=xtr, q=3, diag_error_structure=[1, 1, 1], submethod='rep')
+    o = orc.OracleLCGP(y=ytr, x=xtr, q=3, diag_error_structure=[1, 1, 1], submethod='rep')
+    _check(m, o, synth.param_points(1, o.get_unconstrained()))
+
+
+def _golden_model(name):
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden'))
+    import make_golden
+    for nm, c, om, x0 in make_golden.case_models():
+        if nm == name:
+            return om
+    raise KeyError(name)
+
+
+@pytest.mark.parametrize('name', ['kat_rep', 'full_n64', 'full_n150_grouped', 'rep_n70', 'rep_n33_raw', 'cfg2_n1024'])
+def test_committed_golden_vectors(name):
+    om = _golden_model(name)
+    kw = dict(q=om.q, submethod=om.submethod, diag_error_structure=om.diag_error_structure,
+              robust_mean=om.robust_mean, rep_standardize_ybar=om.rep_standardize_ybar)
+    m = LCGP(y=om.y_orig, x=om.x_orig, **kw)
+    # gradients do not depend on the SVD signs, predictions neither; compare directly with the fixtures
+    for i, u in enumerate(GOLD[name + '/u']):
+        v, g = m.loss_and_grad(u)
+        assert abs(v - GOLD[name + '/nll'][i]) <= NLL_RTOL * abs(GOLD[name + '/nll'][i])
+        gg = GOLD[name + '/grad'][i]
+        assert np.max(np.abs(g - gg)) <= GRAD_RTOL * np.max(np.abs(gg))
+    if name + '/x0' in GOLD:
+        m._set_flat(GOLD[name + '/u'][1])
+        out = m.predict(GOLD[name + '/x0'], return_fullcov=(om.submethod == 'full'))
+        np.testing.assert_allclose(out[0].numpy(), GOLD[name + '/ypred'], rtol=1e-6, atol=1e-8)
+        np.testing.assert_allclose(out[1].numpy(), GOLD[name + '/ypredvar'], rtol=1e-6, atol=1e-9)
+        np.testing.assert_allclose(out[2].numpy(), GOLD[name + '/yconfvar'], rtol=1e-6, atol=1e-9)
+        if om.submethod == 'full':
+            np.testing.assert_allclose(out[3].numpy(), GOLD[name + '/fullcov'], rtol=1e-6, atol=1e-9)
+
+
+def test_kat2_fit_predict_on_the_gpu_matches_the_reference_notebook():
+    xtr, ytr, xte, ytrue = kd.kat_dataset()
+    m = LCGP(y=ytr, x=xtr, q=3, diag_error_structure=[1, 1, 1], robust_mean=True, submethod='rep')
+    np.testing.assert_allclose(m.diag_D.numpy(), kd.KAT_DIAG_D, atol=5e-9, rtol=0)
+    before = float(m.loss())
+    m.fit()
+    assert float(m.loss()) < before
+    lLmb, _, ls2, _ = m.get_param()
+    np.testing.assert_allclose(lLmb.numpy()[:, 0], kd.KAT_LENGTHSCALES, rtol=1e-3)
+    np.testing.assert_allclose(ls2.numpy(), kd.KAT_LSIGMA2S, atol=1e-3)
+    mean, pvar, cvar = (t.numpy() for t in m.predict(xte))
+    assert abs(orc.rmse(ytrue, mean) - kd.KAT_RMSE) < 5e-5
+    assert abs(orc.normalized_rmse(ytrue, mean) - kd.KAT_NRMSE) < 5e-5
+    cover, width = orc.intervalstats(ytrue, mean, cvar)
+    assert abs(cover - kd.KAT_COVER) < 5e-4 and abs(width - kd.KAT_WIDTH) < 5e-5
+    assert abs(orc.dss_diag(ytrue, mean, cvar) - kd.KAT_DSS) < 2e-4
+
+
+def test_matern32_matches_covmat_restatement():
+    rng = np.random.default_rng(0)
+    x1 = rng.standard_normal((40, 2))
+    x2 = rng.standard_normal((25, 2))
+    for a, b in ((x1, x2), (x1, x1)):
+        got = Matern32(a, b, [0.7, 1.3], 1.7, 3e-3).numpy()
+        want = orc.matern32(a, b, [0.7, 1.3], 1.7, 3e-3)
+        np.testing.assert_allclose(got, want, rtol=1e-14, atol=1e-16)
+    np.testing.assert_allclose(Matern32(x1, x1, [0.7, 1.3], 1.7, 3e-3, diag_only=True).numpy(), 1.7)
+    x = np.linspace(0, 1, 40).reshape(40, 1)
+    Matern32(x1=x, x2=np.linspace(0, 1, 25).reshape(25, 1), llmb=1., llmb0=1., lnug=-12.)
+    with pytest.raises(AssertionError):
+        Matern32(np.linspace(0, 1, 40), np.linspace(0, 1, 40), 1., 1., -12.)
+
+
+def test_predict_matches_oracle_and_nugget_at_training_inputs():
+    x, y = synth.make_full(31, 150, 3, 4, 3)
+    m = LCGP(y=y, x=x, q=3)
+    o = orc.OracleLCGP(y=y, x=x, q=3)
+    o.phi = m.phi.numpy().copy()
+    u = synth.param_points(31, o.get_unconstrained())[2]
+    m._set_flat(u)
+    o.set_unconstrained(u)
+    for x0 in (np.random.default_rng(1).uniform(0, 1, (70, 3)), x):
+        got = m.predict(x0, return_fullcov=True)
+        want = o.predict(x0, return_fullcov=True)
+        for a, b in zip(got, want):
+            np.testing.assert_allclose(a.numpy(), b, rtol=1e-6, atol=1e-9)
+    np.testing.assert_allclose(m.CinvMs.numpy(), o._aux_full()['CinvMs'], rtol=1e-6, atol=1e-9)
+    th = m.Ths.numpy()
+    np.testing.assert_allclose(th @ np.transpose(th, (0, 2, 1)),
+                               np.einsum('kij,kjl->kil', o._aux_full()['Ths'], o._aux_full()['Ths']), rtol=1e-6, atol=1e-9)
+
+
+def test_fp32_path_against_fp64_path():
+    """The reference is float64 only; the fp32 variant is compared with this build's own fp64 result."""
+    x, y = synth.make_full(41, 700, 4, 6, 3)
+    m64 = LCGP(y=y, x=x, q=3)
+    m32 = LCGP(y=y, x=x, q=3, dtype='float32')
+    u = m64._get_flat()
+    v64, g64 = m64.loss_and_grad(u)
+    v32, g32 = m32.loss_and_grad(u)
+    assert abs(v32 - v64) <= 2e-4 * abs(v64)
+    assert np.max(np.abs(g32 - g64)) <= 2e-2 * np.max(np.abs(g64))
+
+
+def test_not_positive_definite_is_reported():
+    x, y = synth.make_full(42, 100, 2, 3, 2)
+    m = LCGP(y=y, x=x, q=2)
+    m.diag_D = torch.as_tensor(np.array([-50.0, 1.0]))       # forces a negative pivot in component 0
+    with pytest.raises(np.linalg.LinAlgError):
+        m.loss()
+
+
+# ---- BASELINE.json full size (n=4096, d=6, q=8): size-independent properties + NLL vs the oracle -------------
+@pytest.fixture(scope='module')
+def cfg3():
+    x, y, cfg = synth.make_config(3)
+    return x, y, cfg, LCGP(y=y, x=x, q=cfg['q'])
+
+
+def test_cfg3_directional_derivative(cfg3):
+    x, y, cfg, m = cfg3
+    u = synth.param_points(3, m._get_flat())[1]
+    v0, g = m.loss_and_grad(u)
+    rng = np.random.default_rng(3)
+    dirn = rng.standard_normal(u.shape)
+    dirn /= np.linalg.norm(dirn)
+    h = 1e-5
+    vp, _ = m.loss_and_grad(u + h * dirn)
+    vm, _ = m.loss_and_grad(u - h * dirn)
+    fd = (vp - vm) / (2 * h)
+    assert abs(fd - g @ dirn) <= 1e-5 * max(1.0, abs(g @ dirn)), (fd, g @ dirn)
+
+
+def test_cfg3_inverse_times_matrix_is_identity_on_sampled_columns(cfg3):
+    x, y, cfg, m = cfg3
+    m.loss_and_grad(m._get_flat())
+    lLmb, lLmb0, _, lnug = (t.numpy() for t in m.get_param())
+    k = 5
+    ainv = m._engine.fetch_matrix(2, k)
+    cols = [0, 63, 64, 2047, 4095]
+    ck = orc.matern32(m.x.numpy(), m.x.numpy()[cols], lLmb[k], lLmb0[k], lnug[k])
+    nt = lnug[k] / (1 + lnug[k])
+    acols = m.diag_D.numpy()[k] * ck
+    for j, c in enumerate(cols):     # matern32 adds no nugget for a rectangular block: add it by hand
+        acols[c, j] += 1.0 + m.diag_D.numpy()[k] * lLmb0[k] * nt
+    ident = ainv @ acols
+    want = np.zeros_like(ident)
+    for j, c in enumerate(cols):
+        want[c, j] = 1.0
+    assert np.max(np.abs(ident - want)) < 1e-9
+
+
+def test_cfg3_nll_matches_oracle(cfg3):
+    x, y, cfg, m = cfg3
+    o = orc.OracleLCGP(y=y, x=x, q=cfg['q'])
+    o.phi = m.phi.numpy().copy()
+    u = synth.param_points(3, o.get_unconstrained())[2]
+    v1, _ = m.loss_and_grad(u)
+    o.set_unconstrained(u)
+    v2 = o.loss()
+    assert abs(v1 - v2) <= NLL_RTOL * abs(v2), (v1, v2)
+
+
+def test_full_equals_n_times_rep_at_scale():
+    """r_i = 1 identity at n = 2048: exercises the rep scaling path at a multi-tile size."""
+    x, y = synth.make_full(51, 2048, 3, 6, 4)
+    mf = LCGP(y=y, x=x, q=4)
+    mr = LCGP(y=y, x=x, q=4, submethod='rep')
+    order = np.lexsort(x.T[::-1])
+    np.testing.assert_allclose(mr.x_unique.numpy(), x[order])
+    mr.phi = mf.phi.clone()
+    u = synth.param_points(51, mf._get_flat())[1]
+    mf._set_flat(u)
+    mr._set_flat(u)
+    mr.lsigma2s.assign(mf.lsigma2s.numpy() + 2.0 * np.log(mf.ystd.numpy()[:, 0]))
+    a = float(mf.loss())
+    b = int(mr.n) * float(mr.loss())
+    assert abs(a - b) <= 1e-9 * abs(a), (a, b)

@@ -1,0 +1,298 @@
+"""CPU tests of the host side of lcgp_amd: constructor contract of the reference's tests
+(test_initialize.py, test_standardization.py, test_rep.py sections 1-2, test_coverage_gaps.py), exact
+preprocessing vs the oracle and the notebook KAT-1, and the assembly / chain rule around the hot path
+(checked through the test-only OracleEngine stand-in)."""
+import copy
+
+import numpy as np
+import pytest
+import torch
+
+from lcgp_amd import LCGP
+from lcgp_amd import synth
+from lcgp_amd.params import SoftClip
+from oracle import lcgp_oracle as orc
+from tests import kat_data as kd
+from tests.helpers import patch_engine
+
+
+def _rep_data(seed=0, n_unique=20, p=4, d=2, reps=3):
+    rng = np.random.default_rng(seed)
+    xu = rng.uniform(0, 1, (n_unique, d))
+    return np.tile(xu, (reps, 1)), rng.standard_normal((p, n_unique * reps)), xu
+
+
+# ---- constructor contract (reference test_initialize.py) -------------------------------------------------
+def test_1d_y_rejected_1d_x_accepted():
+    x = np.linspace(0, 1, 40)
+    with pytest.raises(AssertionError):
+        LCGP(y=copy.copy(x), x=x)
+    m = LCGP(y=x.reshape(1, 40), x=x)
+    assert m.x.shape == (40, 1) and int(m.n.numpy()) == 40 and m.q == 1
+    m.tx_x(m.x)
+    m.tx_y(m.y)
+    print(m)
+
+
+@pytest.mark.parametrize('err', [[2, 1], [1, 1, 1], None, [1, 2]])
+def test_valid_error_structures(err):
+    LCGP(y=np.random.randn(3, 40), x=np.random.randn(40, 5), diag_error_structure=err)
+
+
+@pytest.mark.parametrize('err', [[1, 1], [0, 1, 1], [2, 2]])
+def test_invalid_error_structures(err):
+    with pytest.raises(AssertionError):
+        LCGP(y=np.random.randn(3, 40), x=np.random.randn(40, 5), diag_error_structure=err)
+
+
+def test_q_and_threshold_exclusive_and_threshold_rule():
+    x = np.linspace(0, 1, 40)
+    y = np.random.default_rng(0).standard_normal((3, 40))
+    with pytest.raises(ValueError):
+        LCGP(y=y, x=x, q=2, var_threshold=0.9)
+    m = LCGP(y=y, x=x, var_threshold=0.9)
+    s = np.linalg.svd(m.y.numpy(), compute_uv=False)
+    cum = np.cumsum(s ** 2) / np.sum(s ** 2)
+    assert m.q == int(np.argmax(cum > 0.9) + 1)
+
+
+def test_mismatch_and_bad_submethod():
+    with pytest.raises(AssertionError):
+        LCGP(y=np.random.randn(3, 25), x=np.linspace(0, 1, 40))
+    with pytest.raises(ValueError):
+        LCGP(y=np.random.randn(3, 40), x=np.linspace(0, 1, 40), submethod='null')
+
+
+def test_accepts_torch_inputs():
+    x = torch.rand(30, 2, dtype=torch.float32)
+    y = torch.randn(3, 30)
+    m = LCGP(y=y, x=x)
+    assert m.x.dtype == torch.float64 and m.y.dtype == torch.float64
+
+
+# ---- standardisation (reference test_standardization.py) ----------------------------------------------------
+def test_standard_x_and_xnorm_match_reference_definition():
+    x = np.random.default_rng(1).uniform(-2, 5, (60, 3))
+    x[7] = x[3]                                   # duplicated rows -> zero distances are excluded
+    xs, xmin, xmax, xo, xnorm = LCGP.init_standard_x(torch.as_tensor(x))
+    assert xs.shape == (60, 3) and float(xs.min()) == 0.0 and float(xs.max()) == 1.0
+    np.testing.assert_allclose(xnorm.numpy(), orc.xnorm_pairs(x), rtol=1e-12)
+    assert np.all(xnorm.numpy() > 0)
+
+
+@pytest.mark.parametrize('robust', [True, False])
+def test_standard_y_roundtrip_and_oracle(robust):
+    x, y = synth.make_full(3, 51, 2, 4, 3)
+    m = LCGP(y=y, x=x, robust_mean=robust)
+    np.testing.assert_allclose(m.tx_y(m.y).numpy(), y, atol=1e-10)
+    c, s = orc.center_spread(y, robust, guard_zero=False)
+    np.testing.assert_array_equal(m.ymean.numpy(), c)
+    np.testing.assert_array_equal(m.ystd.numpy(), s)
+
+
+# ---- replication preprocessing (reference test_rep.py 1-2, test_coverage_gaps.py) ------------------------------
+def test_rep_structures():
+    x, y, xu = _rep_data(n_unique=15, reps=4, p=3, d=2)
+    m = LCGP(y=y, x=x, submethod='rep')
+    for attr in ['x_unique', 'x_unique_s', 'ybar', 'ybar_s', 'ybar_mean', 'ybar_std', 'r', 'R', 'group_ids']:
+        assert hasattr(m, attr)
+    assert int(m.n.numpy()) == 15 and m._rep_initialized is True
+    assert np.all(m.r.numpy() == 4)
+    np.testing.assert_array_equal(torch.diagonal(m.R).numpy(), m.r.numpy().astype(float))
+    _, inv, _ = np.unique(x, axis=0, return_inverse=True, return_counts=True)
+    for i in range(15):
+        np.testing.assert_allclose(m.ybar.numpy()[:, i], y[:, np.asarray(inv).reshape(-1) == i].mean(axis=1), atol=1e-10)
+    xs = m.x_unique_s.numpy()
+    assert xs.min() >= -1e-9 and xs.max() <= 1 + 1e-9
+    out = m.preprocess(x_raw=x, y_raw=y)
+    assert len(out) == 12 and int(out[9].numpy()) == 15 and int(out[10].numpy()) == 2 and int(out[11].numpy()) == 3
+    assert out[4].shape == (15, 15) and out[6].shape == (3, 15)
+    assert int(m.preprocess()[9].numpy()) == 15
+
+
+def test_ensure_replication_spy():
+    x, y, _ = _rep_data(n_unique=15, reps=4, p=3)
+    m = LCGP(y=y, x=x, submethod='rep')
+    calls = {'n': 0}
+    orig = m.preprocess
+
+    def spy(*a, **k):
+        calls['n'] += 1
+        return orig(*a, **k)
+    m.preprocess = spy
+    m._ensure_replication()
+    assert calls['n'] == 0
+    m._rep_initialized = False
+    m._ensure_replication()
+    assert calls['n'] == 1 and m._rep_initialized is True
+
+
+def test_phi_input_fallbacks_and_nonrobust_center():
+    x, y, _ = _rep_data(n_unique=15, reps=4, p=3)
+    m = LCGP(y=y, x=x, submethod='rep', rep_standardize_ybar=False, robust_mean=False)
+    np.testing.assert_allclose(m._get_phi_input().numpy(), m.ybar.numpy())
+    c, s = m._compute_center_spread_tf(m.ybar)
+    np.testing.assert_allclose(c.numpy()[:, 0], m.ybar.numpy().mean(axis=1))
+    np.testing.assert_allclose(s.numpy()[:, 0], m.ybar.numpy().std(axis=1))
+    m2 = LCGP(y=y, x=x, submethod='rep')
+    del m2.ybar_s
+    del m2.ybar
+    np.testing.assert_allclose(m2._get_phi_input().numpy(), m2.y.numpy())
+
+
+# ---- exact preprocessing vs the oracle and the notebook -------------------------------------------------------
+def test_kat1_through_the_product_host_side():
+    xtr, ytr, _, _ = kd.kat_dataset()
+    m = LCGP(y=ytr, x=xtr, q=3, diag_error_structure=[1, 1, 1], submethod='rep')
+    np.testing.assert_allclose(m.diag_D.numpy(), kd.KAT_DIAG_D, atol=5e-9, rtol=0)
+    np.testing.assert_allclose(np.var(m.g.numpy(), axis=1), kd.KAT_VAR_G, atol=5e-9, rtol=0)
+    assert int(m.n.numpy()) == kd.KAT_N_UNIQUE and int(m.r.numpy().sum()) == kd.KAT_N_TOTAL
+
+
+@pytest.mark.parametrize('mode', ['full', 'rep'])
+def test_initial_state_equals_oracle(mode):
+    if mode == 'full':
+        x, y = synth.make_full(4, 37, 3, 5, 3)
+        kw = dict(q=3, diag_error_structure=[2, 3])
+    else:
+        x, y = synth.make_rep(4, 21, 3, 2, 4, 4)
+        kw = {}
+    m = LCGP(y=y, x=x, submethod=mode, **kw)
+    o = orc.OracleLCGP(y=y, x=x, submethod=mode, **kw)
+    np.testing.assert_allclose(m.diag_D.numpy(), o.diag_D, rtol=1e-12)
+    np.testing.assert_allclose(np.abs(m.phi.numpy()), np.abs(o.phi), rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(m._get_flat(), o.get_unconstrained(), rtol=1e-12, atol=1e-12)
+    for a, b in zip(m.get_param(), o.get_param()):
+        np.testing.assert_allclose(a.numpy(), b, rtol=1e-12)
+    names = [v.name for v in m.trainable_variables]
+    assert len(names) == 4 and all(np.all(np.isfinite(v.numpy())) for v in m.trainable_variables)
+
+
+def test_softclip_matches_oracle_formulas():
+    for lo, hi in (orc.LLMB_BOUNDS, orc.LLMB0_BOUNDS, orc.LNUG_BOUNDS):
+        sc = SoftClip(lo, hi)
+        u = np.linspace(-4.0, 6.0, 21)
+        np.testing.assert_allclose(sc.forward(u), orc.softclip_forward(u, lo, hi), rtol=1e-13, atol=hi * 1e-15)
+        np.testing.assert_allclose(sc.dforward(u), orc.softclip_grad(u, lo, hi), rtol=1e-12)
+        v = sc.forward(u)
+        np.testing.assert_allclose(sc.forward(sc.inverse(v)), v, rtol=1e-9, atol=hi * 1e-15)
+
+
+# ---- host assembly around the hot path, through the stand-in engine -----------------------------------------------
+@pytest.mark.parametrize('mode,kw', [('full', dict(q=3)), ('full', dict(q=2, diag_error_structure=[1, 3], robust_mean=False)),
+                                     ('rep', {}), ('rep', dict(rep_standardize_ybar=False))])
+def test_assembly_and_chain_rule_equal_oracle(mode, kw):
+    if mode == 'full':
+        x, y = synth.make_full(6, 45, 2, 4, 3)
+    else:
+        x, y = synth.make_rep(6, 18, 3, 2, 4, 4)
+    m = patch_engine(LCGP(y=y, x=x, submethod=mode, **kw))
+    o = orc.OracleLCGP(y=y, x=x, submethod=mode, **kw)
+    o.phi = m.phi.numpy().copy()
+    for u in synth.param_points(6, o.get_unconstrained()):
+        v1, g1 = m.loss_and_grad(u)
+        v2, g2 = o.loss_and_grad_unconstrained(u)
+        assert abs(v1 - v2) <= 1e-12 * max(1.0, abs(v2))
+        np.testing.assert_allclose(g1, g2, rtol=1e-10, atol=1e-12 * np.max(np.abs(g2)))
+    assert abs(float(m.loss()) - o.loss()) <= 1e-12 * abs(o.loss())
+
+
+@pytest.mark.parametrize('mode', ['full', 'rep'])
+def test_predict_and_caches_equal_oracle_through_stand_in(mode):
+    if mode == 'full':
+        x, y = synth.make_full(8, 40, 2, 3, 3)
+    else:
+        x, y = synth.make_rep(8, 16, 3, 2, 4, 4)
+    m = patch_engine(LCGP(y=y, x=x, submethod=mode))
+    o = orc.OracleLCGP(y=y, x=x, submethod=mode)
+    o.phi = m.phi.numpy().copy()
+    u = synth.param_points(8, o.get_unconstrained())[1]
+    m._set_flat(u)
+    o.set_unconstrained(u)
+    x0 = np.random.default_rng(3).uniform(0, 1, (9, 2))
+    got = m.predict(x0, return_fullcov=True)
+    want = o.predict(x0, return_fullcov=True)
+    for a, b in zip(got[:3], want[:3]):
+        assert a.shape == (m.p, 9)
+        np.testing.assert_allclose(a.numpy(), b, rtol=1e-8, atol=1e-10)
+    if mode == 'full':
+        np.testing.assert_allclose(got[3].numpy(), want[3], rtol=1e-8, atol=1e-10)
+        diag = np.diagonal(got[3].numpy(), axis1=1, axis2=2).T
+        np.testing.assert_allclose(diag, got[1].numpy(), rtol=1e-5, atol=1e-6)
+    else:
+        assert got[3] is None
+        aux = o._aux_rep()
+        np.testing.assert_allclose(m.CinvMs.numpy(), aux['CinvMs'], rtol=1e-7, atol=1e-9)
+        np.testing.assert_allclose(m.mks.numpy(), aux['mks'], rtol=1e-7, atol=1e-9)
+        np.testing.assert_allclose(m.Tks.numpy(), aux['Tks'], rtol=1e-5, atol=1e-7)
+    # predicting at the training inputs adds the nugget on the diagonal (covmat.py:46-51)
+    xt = (m.x_unique if mode == 'rep' else m.x_orig).numpy()
+    a = m.predict(xt)[0].numpy()
+    b = o.predict(xt)[0]
+    np.testing.assert_allclose(a, b, rtol=1e-8, atol=1e-10)
+    # cache invalidation: new parameters -> predictions change and equal the oracle's again
+    u2 = synth.param_points(8, o.get_unconstrained())[2]
+    m._set_flat(u2)
+    o.set_unconstrained(u2)
+    np.testing.assert_allclose(m.predict(x0)[0].numpy(), o.predict(x0)[0], rtol=1e-8, atol=1e-10)
+
+
+def test_predict_bad_submethod_keyerror_and_cache_reset():
+    x, y, _ = _rep_data()
+    m = patch_engine(LCGP(y=y, x=x, submethod='rep'))
+    m.CinvMs = torch.full((m.q, int(m.n)), float('nan'), dtype=torch.float64)
+    m.Tks = None
+    m.compute_aux_predictive_quantities()
+    assert m.Tks is not None and not np.any(np.isnan(m.CinvMs.numpy()))
+    assert m.psi_c.shape == (m.q, int(m.p))
+    m.submethod = 'bogus'
+    with pytest.raises(KeyError):
+        m.predict(x0=m.x_unique)
+    with pytest.raises(ValueError):
+        m.loss()
+
+
+def test_fit_through_stand_in_reduces_loss():
+    x, y, _ = _rep_data()
+    m = patch_engine(LCGP(y=y, x=x, submethod='rep'))
+    before = float(m.loss())
+    m.fit()
+    assert float(m.loss()) <= before + 1e-3
+    for v in m.trainable_variables:
+        assert np.all(np.isfinite(v.numpy()))
+
+
+# ---- the C ABI library ---------------------------------------------------------------------------------------------
+def test_c_abi_library_exports_every_declared_symbol():
+    import re
+    from lcgp_amd import _hip
+    _hip.build_library()
+    lib = _hip.load()
+    header = open(_hip.HDR_PATH).read()
+    declared = set(re.findall(r'\b(lcgp_[a-z0-9_]+)\s*\(', header))
+    assert declared == set(_hip.SIGNATURES), declared ^ set(_hip.SIGNATURES)
+    for name in declared:
+        assert hasattr(lib, name)
+    assert lib.lcgp_version() >= 100
+    assert lib.lcgp_theta_width(6, 64) == 6 + 3 + 64 and lib.lcgp_out_width(6, 64) == 6 + 5 + 64
+    import ctypes as C
+    nbytes = C.c_size_t(0)
+    assert lib.lcgp_workspace_bytes(0, 4096, 6, 64, 8, C.byref(nbytes)) == 0
+    assert nbytes.value >= 3 * 8 * 4096 * 4096 * 8
+    assert lib.lcgp_workspace_bytes(0, 4096, 99, 64, 8, C.byref(nbytes)) < 0      # d > 16 refused
+    assert b'd must be' in lib.lcgp_last_error()
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason="checks the no-GPU behaviour")
+def test_hot_path_fails_loudly_without_gpu():
+    x, y = synth.make_full(9, 20, 2, 3, 2)
+    m = LCGP(y=y, x=x)
+    with pytest.raises(RuntimeError, match='no CPU fallback'):
+        m.loss()
+    with pytest.raises(RuntimeError, match='no CPU fallback'):
+        m.fit()
+    from lcgp_amd import Matern32
+    with pytest.raises(RuntimeError):
+        Matern32(x, x, np.ones(2), 1.0, 1e-3)
+    with pytest.raises(AssertionError):
+        Matern32(np.linspace(0, 1, 5), np.linspace(0, 1, 5), 1.0, 1.0, -12.0)
