@@ -25,6 +25,7 @@ import numpy as np  # noqa: E402
 FP64_MFMA_PEAK_TFLOPS = 78.6      # MI355X fp64 matrix (= vector) peak, SURVEY.md 8(d) / BASELINE.md 4
 FP32_MFMA_PEAK_TFLOPS = 157.3
 HBM_PEAK_GBS = 8000.0
+T_START = time.perf_counter()
 
 
 def parse():
@@ -70,21 +71,53 @@ def stage_times(m, reps=3):
     return {k: float(np.median(v)) for k, v in acc.items()}
 
 
-def cpu_baseline(m, x, y, cfg):
-    """Reference algorithm (eigh form + autodiff) and Cholesky form, ONE component of the same workload."""
-    from oracle import cpu_baseline as cb
-    cores = os.cpu_count() or 1
+def log(msg):
+    print('[bench %.1fs] %s' % (time.perf_counter() - T_START, msg), file=sys.stderr, flush=True)
+
+
+def host_cores():
+    """CPU share of this process: affinity mask capped by the cgroup quota (the GPU box gives 16 of many)."""
     try:
         cores = len(os.sched_getaffinity(0))
     except Exception:
+        cores = os.cpu_count() or 1
+    try:
+        quota, period = open('/sys/fs/cgroup/cpu.max').read().split()
+        if quota != 'max':
+            cores = max(1, min(cores, int(float(quota) / float(period))))
+    except Exception:
         pass
+    if os.environ.get('LCGP_CPU_THREADS'):
+        cores = int(os.environ['LCGP_CPU_THREADS'])
+    return cores
+
+
+def cpu_baseline(m, budget_s=40.0):
+    """Reference algorithm (eigh form + autodiff) and Cholesky form for ONE component of the same workload on the
+    host cores.  Bounded: a probe at n=1024 picks the largest prefix of the training set (n, n/2, n/4 ...) whose
+    predicted eigh-form time fits the budget; a shorter prefix is scaled by (n/n_s)^3 and reported as such."""
+    from oracle import cpu_baseline as cb
+    from threadpoolctl import threadpool_limits
+    cores = host_cores()
     lLmb, lLmb0, ls2b, lnug = (t.numpy() for t in m.get_param())
     phi, D = m.phi.numpy(), m.diag_D.numpy()
     xs, ys = m.x.numpy(), m.y.numpy()
-    k = 0
-    t_eigh, v_eigh, g_eigh = cb.eigh_form_component(xs, ys, phi[:, k], D[k], lLmb[k], lLmb0[k], lnug[k], ls2b, threads=cores)
-    t_chol, pieces = cb.chol_form_component(xs, ys, phi[:, k], D[k], lLmb[k], lLmb0[k], lnug[k], ls2b)
-    q = int(m.q)
+    n, q, k = int(m.n), int(m.q), 0
+
+    def run(ns):
+        with threadpool_limits(limits=cores):
+            a = cb.eigh_form_component(xs[:ns], ys[:, :ns], phi[:, k], D[k], lLmb[k], lLmb0[k], lnug[k], ls2b, threads=cores)
+            b = cb.chol_form_component(xs[:ns], ys[:, :ns], phi[:, k], D[k], lLmb[k], lLmb0[k], lnug[k], ls2b)
+        return a, b
+    probe_n = min(n, 1024)
+    (t_probe, _, _), _ = run(probe_n)
+    log('cpu probe: eigh-form component at n=%d took %.2f s on %d threads' % (probe_n, t_probe, cores))
+    ns = n
+    while ns > probe_n and t_probe * (ns / probe_n) ** 3 > budget_s:
+        ns //= 2
+    (t_eigh, v_eigh, g_eigh), (t_chol, pieces) = run(ns)
+    log('cpu sample: n_s=%d eigh-form %.2f s, chol-form %.2f s' % (ns, t_eigh, t_chol))
+    scale = (n / ns) ** 3
     model = ''
     try:
         for line in open('/proc/cpuinfo'):
@@ -93,11 +126,18 @@ def cpu_baseline(m, x, y, cfg):
                 break
     except Exception:
         pass
-    return dict(value=1.0 / (q * t_eigh), unit='evals/s', cores=cores, kind='port',
-                sample='1 of %d components at n=%d (eigh-form NLL + autodiff gradient, torch CPU fp64, %.1f s), '
-                       'scaled by q' % (q, int(m.n), t_eigh),
-                cpu_model=model, eigh_form_s_per_component=t_eigh, chol_form_s_per_component=t_chol,
-                chol_form_evals_per_s=1.0 / (q * t_chol)), pieces, (v_eigh, g_eigh)
+    sample = '1 of %d components, first %d of %d inputs (eigh-form NLL + autodiff gradient, torch CPU fp64, %.1f s)' \
+             % (q, ns, n, t_eigh)
+    sample += ', scaled by q' + ('' if ns == n else ' and by (n/n_s)^3 = %g' % scale)
+    base = dict(value=1.0 / (q * t_eigh * scale), unit='evals/s', cores=cores, kind='port', sample=sample,
+                cpu_model=model, n_sample=ns, eigh_form_s_per_component=t_eigh * scale,
+                chol_form_s_per_component=t_chol * scale, chol_form_evals_per_s=1.0 / (q * t_chol * scale))
+    return base, pieces, ns
+
+
+def _lk(m):
+    m._get_engine()
+    return m._local_ks
 
 
 def main():
@@ -127,6 +167,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    log('model built: n=%d d=%d p=%d q=%d, %d local components' % (int(m.n), int(m.d), int(m.p), int(m.q), len(_lk(m))))
     last = None
     for i in range(args.warmup):
         last = m.loss_and_grad(pts[i % len(pts)])
@@ -141,6 +182,7 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 
+    log('timed %d steps: %.3f ms/step' % (args.steps, 1e3 * dt / args.steps))
     n, d, p, q = int(m.n), int(m.d), int(m.p), int(m.q)
     flops_eval = float(q) * float(n) ** 3                       # potrf n^3/3 + inverse 2n^3/3 per component
     peak = FP64_MFMA_PEAK_TFLOPS if dtype == 'float64' else FP32_MFMA_PEAK_TFLOPS
@@ -157,6 +199,7 @@ def main():
     if rank == 0 and not args.no_stages and m._engine is not None:
         m.loss_and_grad(pts[0])
         st = stage_times(m)
+        log('stages (ms): %s' % st)
         ql = len(m._local_ks)
         out['stages_ms'] = st
         # dominant kernel: the single-launch LAUUM (tile_gemm<OP_LAUUM>): A^-1 = W^T W, n^3/3 flops per component
@@ -178,18 +221,23 @@ def main():
         out['build_gbs'] = ql * (n * n / 2.0) * esz / (st['build'] * 1e-3) / 1e9     # lower tiles only are written
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        m.loss_and_grad(pts[0])
-        row = m._engine.out_dev.cpu().numpy()[0]
-        base, pieces, _ = cpu_baseline(m, x, y, cfg)
+        log('cpu baseline (bounded sample) ...')
+        base, pieces, ns = cpu_baseline(m)
         out['cpu_baseline'] = base
-        # parity gate in the same run: component 0, GPU vs the Cholesky-form oracle (NLL 1e-6, gradient 1e-5)
+        # parity gate in the same run, same sample: component 0, HIP path vs the Cholesky-form oracle
+        # (NLL 1e-6 relative, gradient 1e-5 relative to max |g|)
+        from lcgp_amd.engine import HotPathEngine
+        eng = HotPathEngine(m.x.numpy()[:ns], m.y.numpy()[:, :ns], None, 1, dtype, 'cuda:%d' % local_rank)
+        lLmb, lLmb0, ls2b, lnug = (t.numpy() for t in m.get_param())
+        th = np.concatenate([lLmb[0], [lLmb0[0], lnug[0], m.diag_D.numpy()[0]], m.phi.numpy()[:, 0] / np.exp(0.5 * ls2b)])
+        row = eng.evaluate(th[None, :])[0]
         v_gpu = row[0] - row[1] / (2.0 * m.diag_D.numpy()[0])
         g_gpu = row[3:5 + d]
         g_ref = np.concatenate([pieces['g_ell'], [pieces['g_scale'], pieces['g_nug']]])
-        out['parity'] = dict(nll_rel_err=abs(v_gpu - pieces['value']) / abs(pieces['value']),
-                             grad_rel_err=float(np.max(np.abs(g_gpu - g_ref)) / np.max(np.abs(g_ref))),
-                             passed=bool(abs(v_gpu - pieces['value']) <= 1e-6 * abs(pieces['value']) and
-                                         np.max(np.abs(g_gpu - g_ref)) <= 1e-5 * np.max(np.abs(g_ref))))
+        e_v = abs(v_gpu - pieces['value']) / abs(pieces['value'])
+        e_g = float(np.max(np.abs(g_gpu - g_ref)) / np.max(np.abs(g_ref)))
+        out['parity'] = dict(nll_rel_err=e_v, grad_rel_err=e_g, n_sample=ns, passed=bool(e_v <= 1e-6 and e_g <= 1e-5))
+        del eng
     if rank == 0:
         print(json.dumps(out))
     if world > 1:
