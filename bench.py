@@ -154,7 +154,11 @@ def main():
         dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
     assert world == args.gpus, 'launch with torch.distributed.run --nproc-per-node %d' % args.gpus
 
-    from lcgp_amd import LCGP, synth
+    from lcgp_amd import LCGP, synth, _hip
+    if os.environ.get('LCGP_OB'):
+        _hip.check(_hip.load().lcgp_set_tuning(0, int(os.environ['LCGP_OB'])), 'lcgp_set_tuning')
+    if os.environ.get('LCGP_GROUPS'):
+        _hip.check(_hip.load().lcgp_set_tuning(1, int(os.environ['LCGP_GROUPS'])), 'lcgp_set_tuning')
     over = {} if args.n is None else dict(n=args.n)
     x, y, cfg = synth.make_config(args.config, **over)
     dtype = 'float64' if cfg['dtype'] == 'f64' else 'float32'

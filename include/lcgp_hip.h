@@ -9,7 +9,8 @@
  *  - every pointer is a DEVICE pointer on the current device unless marked "host";
  *  - matrices are row-major;  `dtype`: 0 = float64, 1 = float32 (the reference is float64 only);
  *  - `stream` is a hipStream_t passed as void* (NULL = the null stream); every call only ENQUEUES
- *    work on that stream and returns; nothing is allocated, freed or synchronised inside;
+ *    work ordered after / before that stream and returns; no device memory is allocated, freed or
+ *    synchronised inside (lcgp_nll_grad keeps a few internal streams and events, see lcgp_shutdown);
  *  - the caller owns all memory, including `workspace` (size from lcgp_workspace_bytes);
  *  - return value 0 = enqueued; < 0 = bad argument / HIP error (see lcgp_last_error()).
  *    A non positive-definite matrix is reported through the `info` word of the output block,
@@ -49,6 +50,15 @@ const char* lcgp_last_error(void);
 /* width of the theta / output blocks described above. */
 int lcgp_theta_width(int d, int p);
 int lcgp_out_width(int d, int p);
+
+/* performance knobs (process-wide, for experiments; results do not depend on them beyond rounding):
+ *   key 0: width of the outer Cholesky panel in 64-column blocks (default 4);
+ *   key 1: number of component groups whose factorisation chains run on internal streams (default 1 = off, max 8). */
+int lcgp_set_tuning(int key, int value);
+
+/* lcgp_nll_grad overlaps the dependent launch chains of different components on a few internal HIP streams
+ * (created on first use, one set per device, kept for the life of the process).  lcgp_shutdown destroys them. */
+int lcgp_shutdown(void);
 
 /* bytes of `workspace` needed by lcgp_nll_grad / lcgp_potrf_logdet / lcgp_potri for q_local components. */
 int lcgp_workspace_bytes(int dtype, int n, int d, int p, int q_local, size_t* bytes /*host out*/);
@@ -110,7 +120,7 @@ int lcgp_nll_grad(void* stream, int dtype, int n, int d, int p, int q_local,
  *     gvar[k, :] = scale_k - D_k rowsum((c0k o sr) A_k^-1 (c0k o sr)^T)   (lcgp.py:832 / 891-894)
  * using A_k^-1 and z_k left in the workspace by the last lcgp_nll_grad call with the same theta.
  * `same` as in lcgp_matern32 (nugget on the diagonal when x0 is the training set itself).
- * scratch: 2 * n0pad * npad elements of dtype (n0pad, npad = n0, n rounded up to 64). */
+ * scratch: 2 * n0pad * npad elements of dtype (n0pad = n0 rounded up to 64, npad = n rounded up to 128). */
 int lcgp_predict(void* stream, int dtype, int n, int d, int p, int q_local,
                  const void* x, const void* sr, const double* theta, const void* workspace,
                  int n0, const void* x0, int same, void* scratch,

@@ -24,6 +24,8 @@ SIGNATURES = {
     "lcgp_last_error": (C.c_char_p, []),
     "lcgp_theta_width": (_i, [_i, _i]),
     "lcgp_out_width": (_i, [_i, _i]),
+    "lcgp_set_tuning": (_i, [_i, _i]),
+    "lcgp_shutdown": (_i, []),
     "lcgp_workspace_bytes": (_i, [_i, _i, _i, _i, _i, C.POINTER(C.c_size_t)]),
     "lcgp_matern32": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, C.POINTER(_d), _d, _d, _i, _vp]),
     "lcgp_kernel_build": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),

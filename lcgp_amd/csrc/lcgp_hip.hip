@@ -25,8 +25,6 @@ namespace {
 
 constexpr int TS = 64;    // tile size (rows/cols of one tile)
 constexpr int KT = 16;    // k extent of one LDS stage
-constexpr int LDM = 80;   // LDS leading dimension of a [k][m] stage: 80 = 16 (mod 32) -> the two k rows a
-                          // 32-lane group reads land on disjoint banks (ds_read_b64 / ds_read_b32)
 constexpr int DMAX = 16;  // max input dimension handled by the fused kernels
 
 typedef double d4 __attribute__((ext_vector_type(4)));
@@ -62,7 +60,7 @@ inline size_t align256(size_t x) { return (x + 255) & ~size_t(255); }
 inline Ws carve(int dtype, int n, int d, int p, int q, void* base) {
     Ws w;
     w.n = n; w.d = d; w.p = p; w.q = q;
-    w.npad = round_up(n, TS);
+    w.npad = round_up(n, 2 * TS);   // whole 128x128 super-tiles (identity padding)
     w.nb = w.npad / TS;
     w.esz = dtype == LCGP_F64 ? 8 : 4;
     w.mat = (size_t)w.npad * w.npad;
@@ -222,13 +220,55 @@ __global__ __launch_bounds__(256) void cross_kernel(T* __restrict__ out, int ldo
 }
 
 // ---------------------------------------------------------------------------------------------------
-// K2a: diagonal block.  Factorises the 64x64 block jb of M in LDS (L written back, upper part zeroed),
-// writes its inverse into W (upper part zero), adds sum log L_ii to logdet[k], records info[k].
-// One workgroup per component; accumulation in double also for float matrices.
+// K2a: diagonal block.  Factorises the 64x64 block jb of M (L written back, upper part zeroed), writes its
+// inverse into W (upper part zero), adds sum log L_ii to logdet[k], records info[k].  One workgroup per
+// component.  The block lives in REGISTERS (thread (cj, rg) owns rows rg, rg+4, .. of column cj); per pivot
+// the un-scaled pivot column goes through a double-buffered 64-entry LDS line, so the 64-step chain costs one
+// barrier per step, and the update uses a_ij -= c_i (c_j / c_ss) so no sqrt sits on the chain.  The scaling
+// by 1/sqrt(pivot), the log-determinant and the blocked (16) triangular inverse run after the chain.
 // ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double fast_rcp(double a) {
+    // v_rcp_f64 (~26 bits) + two Newton steps: full double accuracy without the IEEE division sequence
+    double x = __builtin_amdgcn_rcp(a);
+    x = fma(fma(-a, x, 1.0), x, x);
+    x = fma(fma(-a, x, 1.0), x, x);
+    return x;
+}
+
+// 16 pivot steps [s0, s0 + 16) of the in-register Cholesky; rows rg + 4m with m < M0 lie above the pivots of this
+// group and are skipped statically.  colbuf is permuted so that the 16 column entries a wave needs (rows rg + 4m)
+// are contiguous: row i sits at (i & 3) * 16 + (i >> 2).
+template <int M0>
+__device__ __forceinline__ void leaf_pivot_group(double (&r)[16], double (*colbuf)[TS], int s0, int cj, int rg,
+                                                 double& piv, int& first_bad, int jb) {
+#pragma unroll 1
+    for (int s = s0; s < s0 + 16; ++s) {
+        double* cb = colbuf[s & 1];
+        if (cj == s) {
+#pragma unroll
+            for (int m = M0; m < 16; ++m) cb[rg * 16 + m] = r[m];
+        }
+        __syncthreads();
+        const double css = cb[((s & 3) << 4) + (s >> 2)];
+        const double ccj = cb[((cj & 3) << 4) + (cj >> 2)];
+        double c[16];
+#pragma unroll
+        for (int m = M0; m < 16; ++m) c[m] = cb[rg * 16 + m];     // wave-uniform address: LDS broadcast
+        if (!(css > 0.0) && first_bad == 0) first_bad = jb * TS + s + 1;
+        if (cj == s) piv = css;
+        if (cj > s) {
+            const double tt = ccj * fast_rcp(css);
+#pragma unroll
+            for (int m = M0; m < 16; ++m) r[m] = fma(-c[m], tt, r[m]);
+        }
+    }
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void leaf_kernel(T* __restrict__ M, T* __restrict__ W, size_t mat, int npad, int jb,
                                                    double* __restrict__ logdet, int* __restrict__ info) {
+    __shared__ double colbuf[2][TS];
+    __shared__ double dinv[TS];
     __shared__ double a[TS][TS + 1];
     __shared__ double w[TS][TS + 1];
     __shared__ double t[TS][TS + 1];
@@ -238,50 +278,53 @@ __global__ __launch_bounds__(256) void leaf_kernel(T* __restrict__ M, T* __restr
     T* Wb = W + (size_t)k * mat + (size_t)jb * TS * npad + (size_t)jb * TS;
     const int cj = tid & 63;
     const int rg = tid >> 6;
+    double r[16];
+#pragma unroll
     for (int m = 0; m < 16; ++m) {
-        int i = rg + 4 * m;
-        a[i][cj] = cj <= i ? (double)Mb[(size_t)i * npad + cj] : 0.0;
-        w[i][cj] = 0.0;
+        const int i = rg + 4 * m;
+        r[m] = cj <= i ? (double)Mb[(size_t)i * npad + cj] : 0.0;
     }
-    double ld_acc = 0.0;
+    double piv = 1.0;
     int first_bad = 0;
-    for (int s = 0; s < TS; ++s) {
-        __syncthreads();
-        double akk = a[s][s];
-        if (!(akk > 0.0) && first_bad == 0) first_bad = jb * TS + s + 1;
-        double dk = sqrt(akk);
-        double inv = 1.0 / dk;
-        ld_acc += log(dk);
-        __syncthreads();
-        if (tid == s) a[s][s] = dk;
-        if (tid > s && tid < TS) a[tid][s] *= inv;
-        __syncthreads();
-        // trailing update of the lower part: (i, cj) with s < cj <= i
-        if (cj > s) {
-            double ljs = a[cj][s];
-            for (int m = 0; m < 16; ++m) {
-                int i = rg + 4 * m;
-                if (i >= cj) a[i][cj] -= a[i][s] * ljs;
-            }
+    leaf_pivot_group<0>(r, colbuf, 0, cj, rg, piv, first_bad, jb);
+    leaf_pivot_group<4>(r, colbuf, 16, cj, rg, piv, first_bad, jb);
+    leaf_pivot_group<8>(r, colbuf, 32, cj, rg, piv, first_bad, jb);
+    leaf_pivot_group<12>(r, colbuf, 48, cj, rg, piv, first_bad, jb);
+    // column cj is final up to the scaling by 1/sqrt(pivot)
+    const double rs = 1.0 / sqrt(piv);
+#pragma unroll
+    for (int m = 0; m < 16; ++m) {
+        const int i = rg + 4 * m;
+        const double l = i >= cj ? r[m] * rs : 0.0;
+        a[i][cj] = l;
+        w[i][cj] = 0.0;
+        Mb[(size_t)i * npad + cj] = (T)l;
+    }
+    if (rg == 0) dinv[cj] = rs;
+    if (tid < TS) {   // wave 0: 1/2 sum log(pivot)
+        double lg = 0.5 * log(piv);
+        for (int off = 32; off > 0; off >>= 1) lg += __shfl_xor(lg, off);
+        if (tid == 0) {
+            logdet[k] += lg;
+            if (first_bad && info[k] == 0) info[k] = first_bad;
         }
     }
     __syncthreads();
-    if (tid == 0) {
-        logdet[k] += ld_acc;
-        if (first_bad && info[k] == 0) info[k] = first_bad;
-    }
     // ---- inverse of the 64x64 lower-triangular block, blocked by 16 ----
-    // (a) the four 16x16 diagonal blocks: thread = one column of one block
+    // (a) the four 16x16 diagonal blocks: thread = one column, kept in registers (solve L w = e_cl)
     if (tid < TS) {
         const int b0 = (tid >> 4) * 16;
         const int cl = tid & 15;
-        const int cg = b0 + cl;
-        w[cg][cg] = 1.0 / a[cg][cg];
-        for (int i = cl + 1; i < 16; ++i) {
-            double s = 0.0;
-            for (int m = cl; m < i; ++m) s += a[b0 + i][b0 + m] * w[b0 + m][cg];
-            w[b0 + i][cg] = -s / a[b0 + i][b0 + i];
+        double wc[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            double sacc = i == cl ? -1.0 : 0.0;
+#pragma unroll
+            for (int m = 0; m < i; ++m) sacc = fma(a[b0 + i][b0 + m], wc[m], sacc);
+            wc[i] = -sacc * dinv[b0 + i];
         }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) w[b0 + i][b0 + cl] = wc[i];
     }
     __syncthreads();
     // (b) off-diagonal blocks by distance:  T_ab = sum_{m=b}^{a-1} L_am W_mb ;  W_ab = -W_aa T_ab
@@ -289,24 +332,27 @@ __global__ __launch_bounds__(256) void leaf_kernel(T* __restrict__ M, T* __restr
     for (int dist = 1; dist < 4; ++dist) {
         for (int bb = 0; bb + dist < 4; ++bb) {
             const int ab = bb + dist;
-            double s = 0.0;
+            double sacc = 0.0;
             for (int mb = bb; mb < ab; ++mb)
-                for (int m = 0; m < 16; ++m) s += a[ab * 16 + ei][mb * 16 + m] * w[mb * 16 + m][bb * 16 + ej];
-            t[ab * 16 + ei][bb * 16 + ej] = s;
+#pragma unroll
+                for (int m = 0; m < 16; ++m) sacc = fma(a[ab * 16 + ei][mb * 16 + m], w[mb * 16 + m][bb * 16 + ej], sacc);
+            t[ab * 16 + ei][bb * 16 + ej] = sacc;
         }
         __syncthreads();
         for (int bb = 0; bb + dist < 4; ++bb) {
             const int ab = bb + dist;
-            double s = 0.0;
-            for (int m = 0; m <= ei; ++m) s += w[ab * 16 + ei][ab * 16 + m] * t[ab * 16 + m][bb * 16 + ej];
-            w[ab * 16 + ei][bb * 16 + ej] = -s;
+            double sacc = 0.0;
+            for (int m = 0; m <= ei; ++m) sacc = fma(w[ab * 16 + ei][ab * 16 + m], t[ab * 16 + m][bb * 16 + ej], sacc);
+            w[ab * 16 + ei][bb * 16 + ej] = -sacc;
         }
         __syncthreads();
     }
+#pragma unroll
     for (int m = 0; m < 16; ++m) {
-        int i = rg + 4 * m;
-        Mb[(size_t)i * npad + cj] = (T)(cj <= i ? a[i][cj] : 0.0);
+        const int i = rg + 4 * m;
         Wb[(size_t)i * npad + cj] = (T)(cj <= i ? w[i][cj] : 0.0);
+        // the 128x128 tile kernels read whole diagonal 128-blocks of W: keep the quadrant above this block zero
+        if ((jb & 1) == 0) Wb[(size_t)i * npad + TS + cj] = (T)0;
     }
 }
 
@@ -325,43 +371,64 @@ struct GemmArgs {
     size_t sA, sB, sC;                          // per-component strides (elements)
     int ldA, ldB, ldC;
     int nb;                                     // number of 64-blocks
-    int p0, p1;                                 // op specific
+    int p0, p1, p2, p3;                         // op specific
 };
 
-template <typename T, int L>
-__device__ __forceinline__ void load_stage(const T* __restrict__ P, int ld, int ks, T (&reg)[4], int tid) {
+// one K-stage (KT = 16 k values) of a TM-row operand tile: global -> registers -> LDS [k][m], ld = TM + 16
+template <typename T, int L, int TM>
+__device__ __forceinline__ void load_stage(const T* __restrict__ P, int ld, int ks, T (&reg)[TM / 16], int tid) {
+    constexpr int EPT = TM / 16;
     if (L == MK) {
-        const int m = tid >> 2, kk = (tid & 3) * 4;
+        constexpr int TPR = KT / EPT;                       // threads per operand row (a row holds 16 k values)
+        const int m = tid / TPR, kk = (tid % TPR) * EPT;
         const T* src = P + (size_t)m * ld + ks + kk;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) reg[e] = src[e];
+        for (int e = 0; e < EPT; ++e) reg[e] = src[e];
     } else {
-        const int kq = tid >> 4, mm = (tid & 15) * 4;
+        const int kq = tid >> 4, mm = (tid & 15) * EPT;
         const T* src = P + (size_t)(ks + kq) * ld + mm;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) reg[e] = src[e];
+        for (int e = 0; e < EPT; ++e) reg[e] = src[e];
     }
 }
 
-template <typename T, int L>
-__device__ __forceinline__ void store_stage(T* __restrict__ S, const T (&reg)[4], int tid) {
+template <typename T, int L, int TM>
+__device__ __forceinline__ void store_stage(T* __restrict__ S, const T (&reg)[TM / 16], int tid) {
+    constexpr int EPT = TM / 16;
+    constexpr int LD = TM + 16;
     if (L == MK) {
-        const int m = tid >> 2, kk = (tid & 3) * 4;
+        constexpr int TPR = KT / EPT;
+        const int m = tid / TPR, kk = (tid % TPR) * EPT;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) S[(kk + e) * LDM + m] = reg[e];
+        for (int e = 0; e < EPT; ++e) S[(kk + e) * LD + m] = reg[e];
     } else {
-        const int kq = tid >> 4, mm = (tid & 15) * 4;
+        const int kq = tid >> 4, mm = (tid & 15) * EPT;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) S[kq * LDM + mm + e] = reg[e];
+        for (int e = 0; e < EPT; ++e) S[kq * LD + mm + e] = reg[e];
     }
 }
 
-template <typename T, int OP>
-__global__ __launch_bounds__(256) void tile_gemm(GemmArgs g) {
+// Workgroups are dealt round-robin over the 8 XCDs (each with its own L2).  Remap the linear tile id so that
+// every XCD works on one contiguous run of tiles (neighbouring tiles share operand panels): bijective for any
+// grid size (speed only, never correctness).
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+    const int q = nwg >> 3, r = nwg & 7, x = bid & 7, i = bid >> 3;
+    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
+}
+
+// TM x TM output tile per 256-thread workgroup (TM = 64: 32x32 per wave, 2x2 MFMA accumulators;
+// TM = 128: 64x64 per wave, 4x4 accumulators -- half the operand traffic per flop).  All tile coordinates
+// (g.nb, g.p0..p3) are in units of TM.
+template <typename T, int OP, int TM>
+__global__ __launch_bounds__(256, TM == 128 ? 2 : 4) void tile_gemm(GemmArgs g) {
     constexpr int LA = (OP == OP_LAUUM) ? KM : MK;
     constexpr int LB = (OP == OP_TRTRI_T || OP == OP_TRTRI_W || OP == OP_LAUUM) ? KM : MK;
-    __shared__ T As[2][KT * LDM];
-    __shared__ T Bs[2][KT * LDM];
+    constexpr int LD = TM + 16;     // = 16 (mod 32): the two k rows a 32-lane group reads hit disjoint banks
+    constexpr int WT = TM / 2;      // rows/cols of the per-wave sub-tile
+    constexpr int MI = WT / 16;     // MFMA tiles per wave per dimension
+    constexpr int EPT = TM / 16;
+    __shared__ T As[2][KT * LD];
+    __shared__ T Bs[2][KT * LD];
 
     const int k = blockIdx.y;
     const T* Ab = (const T*)g.A + (size_t)k * g.sA;
@@ -377,115 +444,136 @@ __global__ __launch_bounds__(256) void tile_gemm(GemmArgs g) {
     if constexpr (OP == OP_TRMM_PANEL) {
         // M[r, j] = M[r, j] * W[j, j]^T for r = j+1+bid      (L21 = A21 L11^-T)
         const int j = g.p0, r = j + 1 + blockIdx.x;
-        A0 = Ab + (size_t)r * TS * g.ldA + (size_t)j * TS; dA = 0;
-        B0 = Bb + (size_t)j * TS * g.ldB + (size_t)j * TS; dB = 0;
+        A0 = Ab + (size_t)r * TM * g.ldA + (size_t)j * TM; dA = 0;
+        B0 = Bb + (size_t)j * TM * g.ldB + (size_t)j * TM; dB = 0;
         nkt = 1;
-        Ct = Cb + (size_t)r * TS * g.ldC + (size_t)j * TS;
+        Ct = Cb + (size_t)r * TM * g.ldC + (size_t)j * TM;
     } else if constexpr (OP == OP_SYRK) {
-        // M[r, c] -= sum_{kt in [p0, p1)} M[r, kt] M[c, kt]^T over the lower tiles with c >= p1
-        int rr, cc;
-        tri_decode(blockIdx.x, rr, cc);
-        const int r = g.p1 + rr, c = g.p1 + cc;
-        A0 = Ab + (size_t)r * TS * g.ldA + (size_t)g.p0 * TS; dA = TS;
-        B0 = Bb + (size_t)c * TS * g.ldB + (size_t)g.p0 * TS; dB = TS;
+        // M[r, c] -= sum_{kt in [p0, p1)} M[r, kt] M[c, kt]^T over the tiles c in [p2, p3), r in [c, nb)
+        // (p3 == nb: the whole trailing triangle; p3 < nb: the rest of the current panel), column-major
+        int t = xcd_remap(blockIdx.x, gridDim.x), c = g.p2;
+        while (t >= g.nb - c) { t -= g.nb - c; ++c; }
+        const int r = c + t;
+        A0 = Ab + (size_t)r * TM * g.ldA + (size_t)g.p0 * TM; dA = TM;
+        B0 = Bb + (size_t)c * TM * g.ldB + (size_t)g.p0 * TM; dB = TM;
         nkt = g.p1 - g.p0;
-        Ct = Cb + (size_t)r * TS * g.ldC + (size_t)c * TS;
+        Ct = Cb + (size_t)r * TM * g.ldC + (size_t)c * TM;
         alpha = -1.0; accumulate = true;
     } else if constexpr (OP == OP_TRTRI_T || OP == OP_TRTRI_W) {
-        // level with block size mb = p0: pair pr covers block rows [2 pr mb, 2 pr mb + 2 mb)
+        // level with block size mb = p0: pair pr covers block rows [2 pr mb, 2 pr mb + 2 mb).
+        // Tiles are enumerated longest-k-loop first (T: cl ascending, W21: rl descending; the pair index is the
+        // fastest one) so that the long tiles start early and the short ones fill the tail.
         const int mb = g.p0;
-        const int per = mb * mb;
-        const int pr = blockIdx.x / per, rem = blockIdx.x - pr * per;
-        const int rl = rem / mb, cl = rem - rl * mb;
+        const int npair = g.p1;
+        const int pr = blockIdx.x % npair, rem = blockIdx.x / npair;
+        int rl, cl;
+        if constexpr (OP == OP_TRTRI_T) { cl = rem / mb; rl = rem - cl * mb; }
+        else { rl = mb - 1 - rem / mb; cl = rem % mb; }
         const int C0 = 2 * pr * mb, R0 = C0 + mb;
         if (R0 + rl >= g.nb) return;
         if constexpr (OP == OP_TRTRI_T) {
             // T[rl, cl] = sum_{kt = cl}^{mb-1} L21[rl, kt] W11[kt, cl]          (A from M, B from W, C into V)
-            A0 = Ab + (size_t)(R0 + rl) * TS * g.ldA + (size_t)(C0 + cl) * TS; dA = TS;
-            B0 = Bb + (size_t)(C0 + cl) * TS * g.ldB + (size_t)(C0 + cl) * TS; dB = (size_t)TS * g.ldB;
+            A0 = Ab + (size_t)(R0 + rl) * TM * g.ldA + (size_t)(C0 + cl) * TM; dA = TM;
+            B0 = Bb + (size_t)(C0 + cl) * TM * g.ldB + (size_t)(C0 + cl) * TM; dB = (size_t)TM * g.ldB;
             nkt = mb - cl;
         } else {
             // W21[rl, cl] = - sum_{kt = 0}^{rl} W22[rl, kt] T[kt, cl]            (A from W, B from V, C into W)
-            A0 = Ab + (size_t)(R0 + rl) * TS * g.ldA + (size_t)R0 * TS; dA = TS;
-            B0 = Bb + (size_t)R0 * TS * g.ldB + (size_t)(C0 + cl) * TS; dB = (size_t)TS * g.ldB;
+            A0 = Ab + (size_t)(R0 + rl) * TM * g.ldA + (size_t)R0 * TM; dA = TM;
+            B0 = Bb + (size_t)R0 * TM * g.ldB + (size_t)(C0 + cl) * TM; dB = (size_t)TM * g.ldB;
             nkt = rl + 1;
             alpha = -1.0;
         }
-        Ct = Cb + (size_t)(R0 + rl) * TS * g.ldC + (size_t)(C0 + cl) * TS;
+        Ct = Cb + (size_t)(R0 + rl) * TM * g.ldC + (size_t)(C0 + cl) * TM;
     } else if constexpr (OP == OP_LAUUM) {
         // V[r, c] = sum_{kt = r}^{nb-1} W[kt, r]^T W[kt, c]
         int r, c;
-        tri_decode(blockIdx.x, r, c);
-        // long k loops first: reverse the row order so the heaviest tiles are scheduled early
-        A0 = Ab + (size_t)r * TS * g.ldA + (size_t)r * TS; dA = (size_t)TS * g.ldA;
-        B0 = Bb + (size_t)r * TS * g.ldB + (size_t)c * TS; dB = (size_t)TS * g.ldB;
+        tri_decode(blockIdx.x, r, c);   // ascending r = longest k loops first; round-robin XCD dealing balances them
+        A0 = Ab + (size_t)r * TM * g.ldA + (size_t)r * TM; dA = (size_t)TM * g.ldA;
+        B0 = Bb + (size_t)r * TM * g.ldB + (size_t)c * TM; dB = (size_t)TM * g.ldB;
         nkt = g.nb - r;
-        Ct = Cb + (size_t)r * TS * g.ldC + (size_t)c * TS;
+        Ct = Cb + (size_t)r * TM * g.ldC + (size_t)c * TM;
     } else {
         // OP_PRED_U: U[m, r] = sum_{kt = 0}^{r} X[m, kt] W[r, kt]^T    (X = scaled cross covariance, n0pad x npad)
         const int r = blockIdx.x % g.nb, m = blockIdx.x / g.nb;
-        A0 = Ab + (size_t)m * TS * g.ldA; dA = TS;
-        B0 = Bb + (size_t)r * TS * g.ldB; dB = TS;
+        A0 = Ab + (size_t)m * TM * g.ldA; dA = TM;
+        B0 = Bb + (size_t)r * TM * g.ldB; dB = TM;
         nkt = r + 1;
-        Ct = Cb + (size_t)m * TS * g.ldC + (size_t)r * TS;
+        Ct = Cb + (size_t)m * TM * g.ldC + (size_t)r * TM;
     }
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
-    const int wm0 = (wave >> 1) * 32, wn0 = (wave & 1) * 32;
+    const int wm0 = (wave >> 1) * WT, wn0 = (wave & 1) * WT;
     typedef typename Mfma<T>::acc_t acc_t;
-    acc_t acc[2][2];
+    acc_t acc[MI][MI];
+    // C -= A B^T: the accumulators start from the C tile (its load overlaps the first operand loads) and the A
+    // fragments are negated, so the epilogue is stores only
+    constexpr bool PRELOAD_C = (OP == OP_SYRK);
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < MI; ++j)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) acc[i][j][e] = 0;
+            for (int e = 0; e < 4; ++e) {
+                if constexpr (PRELOAD_C) {
+                    const int row = wm0 + i * 16 + Mfma<T>::row(lane, e);
+                    const int col = wn0 + j * 16 + (lane & 15);
+                    acc[i][j][e] = Ct[(size_t)row * g.ldC + col];
+                } else {
+                    acc[i][j][e] = 0;
+                }
+            }
 
-    const int nst = nkt * (TS / KT);
-    T ra[4], rb[4];
-    load_stage<T, LA>(A0, g.ldA, 0, ra, tid);
-    load_stage<T, LB>(B0, g.ldB, 0, rb, tid);
+    constexpr int SPT = TM / KT;   // stages per k tile
+    const int nst = nkt * SPT;
+    T ra[EPT], rb[EPT];
+    load_stage<T, LA, TM>(A0, g.ldA, 0, ra, tid);
+    load_stage<T, LB, TM>(B0, g.ldB, 0, rb, tid);
     for (int s = 0; s < nst; ++s) {
         const int buf = s & 1;
-        store_stage<T, LA>(As[buf], ra, tid);
-        store_stage<T, LB>(Bs[buf], rb, tid);
+        store_stage<T, LA, TM>(As[buf], ra, tid);
+        store_stage<T, LB, TM>(Bs[buf], rb, tid);
         __syncthreads();
         if (s + 1 < nst) {
-            const int kt = (s + 1) / (TS / KT), ks = ((s + 1) % (TS / KT)) * KT;
-            load_stage<T, LA>(A0 + (size_t)kt * dA, g.ldA, ks, ra, tid);
-            load_stage<T, LB>(B0 + (size_t)kt * dB, g.ldB, ks, rb, tid);
+            const int kt = (s + 1) / SPT, ks = ((s + 1) % SPT) * KT;
+            load_stage<T, LA, TM>(A0 + (size_t)kt * dA, g.ldA, ks, ra, tid);
+            load_stage<T, LB, TM>(B0 + (size_t)kt * dB, g.ldB, ks, rb, tid);
         }
         const T* as = As[buf];
         const T* bs = Bs[buf];
 #pragma unroll
         for (int kk = 0; kk < KT / 4; ++kk) {
-            const int krow = (kk * 4 + (lane >> 4)) * LDM;
-            T a0 = as[krow + wm0 + (lane & 15)];
-            T a1 = as[krow + wm0 + 16 + (lane & 15)];
-            T b0 = bs[krow + wn0 + (lane & 15)];
-            T b1 = bs[krow + wn0 + 16 + (lane & 15)];
-            acc[0][0] = Mfma<T>::run(a0, b0, acc[0][0]);
-            acc[0][1] = Mfma<T>::run(a0, b1, acc[0][1]);
-            acc[1][0] = Mfma<T>::run(a1, b0, acc[1][0]);
-            acc[1][1] = Mfma<T>::run(a1, b1, acc[1][1]);
+            const int krow = (kk * 4 + (lane >> 4)) * LD;
+            T af[MI], bf[MI];
+#pragma unroll
+            for (int i = 0; i < MI; ++i) {
+                af[i] = PRELOAD_C ? -as[krow + wm0 + i * 16 + (lane & 15)] : as[krow + wm0 + i * 16 + (lane & 15)];
+                bf[i] = bs[krow + wn0 + i * 16 + (lane & 15)];
+            }
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < MI; ++j) acc[i][j] = Mfma<T>::run(af[i], bf[j], acc[i][j]);
         }
     }
-    // the panel TRMM overwrites its own A tile: every wave must be done reading it (it is: all stages
-    // were staged through LDS before the last __syncthreads) -- C is written only after the k loop.
+    // (the panel TRMM overwrites its own A tile: all of it went through LDS before the last barrier)
 #pragma unroll
-    for (int mi = 0; mi < 2; ++mi)
+    for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-        for (int ni = 0; ni < 2; ++ni)
+        for (int ni = 0; ni < MI; ++ni)
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const int row = wm0 + mi * 16 + Mfma<T>::row(lane, e);
                 const int col = wn0 + ni * 16 + (lane & 15);
                 T* dst = Ct + (size_t)row * g.ldC + col;
-                double v = alpha * (double)acc[mi][ni][e];
-                if (accumulate) v += (double)*dst;
-                *dst = (T)v;
+                if constexpr (PRELOAD_C) {
+                    *dst = acc[mi][ni][e];
+                } else {
+                    double v = alpha * (double)acc[mi][ni][e];
+                    if (accumulate) v += (double)*dst;
+                    *dst = (T)v;
+                }
             }
 }
 
@@ -680,12 +768,21 @@ __global__ __launch_bounds__(256) void finalize_kernel(int n, int npad, int d, i
         o[3 + d] = (1.0 - nt) * sums[d] + nt * sums[d + 1];
         o[4 + d] = scale * (sums[d + 1] - sums[d]) / ((1.0 + nug) * (1.0 + nug));
     }
-    for (int a = 0; a < p; ++a) {
-        double s = 0.0;
-        for (int i = tid; i < n; i += 256) s += (double)Y[(size_t)a * n + i] * ((double)bk[i] - (double)zk[i]);
-        s = block_sum(s, sh, tid);
-        if (tid == 0) o[5 + d + a] = s;
-    }
+}
+
+// gsig_a = sum_i Y[a, i] (b_i - z_i): one workgroup per (output a, component)
+template <typename T>
+__global__ __launch_bounds__(256) void gsig_kernel(int n, int npad, int d, int p, const T* __restrict__ Y,
+                                                   const T* __restrict__ b, const T* __restrict__ z,
+                                                   double* __restrict__ out) {
+    __shared__ double sh[4];
+    const int a = blockIdx.x, k = blockIdx.y, tid = threadIdx.x;
+    const T* bk = b + (size_t)k * npad;
+    const T* zk = z + (size_t)k * npad;
+    double s = 0.0;
+    for (int i = tid; i < n; i += 256) s += (double)Y[(size_t)a * n + i] * ((double)bk[i] - (double)zk[i]);
+    s = block_sum(s, sh, tid);
+    if (tid == 0) out[(size_t)k * (d + 5 + p) + 5 + d + a] = s;
 }
 
 // small helpers ----------------------------------------------------------------------------------------
@@ -741,14 +838,23 @@ int do_build(hipStream_t st, const Ws& w, const void* x, const void* sr, const d
     return 0;
 }
 
-template <typename T, int OP>
+template <typename T, int OP, int TM = TS>
 int launch_gemm(hipStream_t st, const GemmArgs& g, int ntiles, int q) {
     if (ntiles <= 0) return 0;
-    hipLaunchKernelGGL((tile_gemm<T, OP>), dim3(ntiles, q), dim3(256), 0, st, g);
+    hipLaunchKernelGGL((tile_gemm<T, OP, TM>), dim3(ntiles, q), dim3(256), 0, st, g);
     CHECK_LAUNCH("tile_gemm");
     return 0;
 }
 
+int g_outer_blocks = 4;   // width of the outer Cholesky panel in 64-blocks (lcgp_set_tuning key 0)
+
+inline int trapezoid_tiles(int nb, int c_lo, int c_hi) {
+    return (c_hi - c_lo) * nb - (c_lo + c_hi - 1) * (c_hi - c_lo) / 2;
+}
+
+// Two-level right-looking Cholesky.  Outer panels of `g_outer_blocks` 64-blocks: inside a panel every 64-column
+// step is  diagonal block -> panel TRMM -> rank-64 update of the REST OF THE PANEL only;  the trailing matrix
+// is touched once per outer panel with K = 64 * g_outer_blocks (read-modify-write traffic / g_outer_blocks).
 template <typename T>
 int do_potrf(hipStream_t st, const Ws& w) {
     T* M = (T*)(w.base + w.off_M);
@@ -757,19 +863,37 @@ int do_potrf(hipStream_t st, const Ws& w) {
     int* info = (int*)(w.base + w.off_info);
     hipLaunchKernelGGL(zero_stats_kernel, dim3((w.q + 63) / 64), dim3(64), 0, st, logdet, info, w.q);
     CHECK_LAUNCH("zero_stats");
-    for (int j = 0; j < w.nb; ++j) {
-        hipLaunchKernelGGL((leaf_kernel<T>), dim3(w.q), dim3(256), 0, st, M, W, w.mat, w.npad, j, logdet, info);
-        CHECK_LAUNCH("leaf_kernel");
-        const int rest = w.nb - 1 - j;
-        if (rest <= 0) break;
-        GemmArgs g;
-        g.A = M; g.B = W; g.C = M; g.sA = g.sB = g.sC = w.mat; g.ldA = g.ldB = g.ldC = w.npad; g.nb = w.nb;
-        g.p0 = j; g.p1 = 0;
-        int rc = launch_gemm<T, OP_TRMM_PANEL>(st, g, rest, w.q);
-        if (rc) return rc;
-        g.A = M; g.B = M; g.C = M; g.p0 = j; g.p1 = j + 1;
-        rc = launch_gemm<T, OP_SYRK>(st, g, rest * (rest + 1) / 2, w.q);
-        if (rc) return rc;
+    GemmArgs g;
+    g.sA = g.sB = g.sC = w.mat; g.ldA = g.ldB = g.ldC = w.npad; g.nb = w.nb;
+    const int ob = g_outer_blocks < 1 ? 1 : g_outer_blocks;
+    for (int J = 0; J < w.nb; J += ob) {
+        const int pe = J + ob < w.nb ? J + ob : w.nb;
+        for (int c = J; c < pe; ++c) {
+            hipLaunchKernelGGL((leaf_kernel<T>), dim3(w.q), dim3(256), 0, st, M, W, w.mat, w.npad, c, logdet, info);
+            CHECK_LAUNCH("leaf_kernel");
+            if (c + 1 >= w.nb) break;
+            g.A = M; g.B = W; g.C = M; g.p0 = c; g.p1 = g.p2 = g.p3 = 0;
+            int rc = launch_gemm<T, OP_TRMM_PANEL>(st, g, w.nb - 1 - c, w.q);
+            if (rc) return rc;
+            if (c + 1 < pe) {
+                g.A = M; g.B = M; g.C = M; g.p0 = c; g.p1 = c + 1; g.p2 = c + 1; g.p3 = pe;
+                rc = launch_gemm<T, OP_SYRK>(st, g, trapezoid_tiles(w.nb, c + 1, pe), w.q);
+                if (rc) return rc;
+            }
+        }
+        if (pe < w.nb) {
+            g.A = M; g.B = M; g.C = M;
+            int rc;
+            if ((ob & 1) == 0) {        // panel boundaries are 128-aligned: 128x128 tiles, K = 64 * ob
+                GemmArgs h = g;
+                h.nb = w.nb / 2; h.p0 = J / 2; h.p1 = pe / 2; h.p2 = pe / 2; h.p3 = w.nb / 2;
+                rc = launch_gemm<T, OP_SYRK, 128>(st, h, trapezoid_tiles(w.nb / 2, pe / 2, w.nb / 2), w.q);
+            } else {
+                g.p0 = J; g.p1 = pe; g.p2 = pe; g.p3 = w.nb;
+                rc = launch_gemm<T, OP_SYRK>(st, g, trapezoid_tiles(w.nb, pe, w.nb), w.q);
+            }
+            if (rc) return rc;
+        }
     }
     return 0;
 }
@@ -780,15 +904,25 @@ int do_trtri(hipStream_t st, const Ws& w) {
     T* W = (T*)(w.base + w.off_W);
     T* V = (T*)(w.base + w.off_V);
     GemmArgs g;
-    g.sA = g.sB = g.sC = w.mat; g.ldA = g.ldB = g.ldC = w.npad; g.nb = w.nb; g.p1 = 0;
-    for (int mb = 1; mb < w.nb; mb *= 2) {
-        const int pairs = (w.nb + 2 * mb - 1) / (2 * mb);
-        g.p0 = mb;
+    g.sA = g.sB = g.sC = w.mat; g.ldA = g.ldB = g.ldC = w.npad; g.p1 = g.p2 = g.p3 = 0;
+    // level 0 joins pairs of 64-blocks (64x64 tiles); every further level works on 128x128 tiles
+    g.nb = w.nb; g.p0 = 1; g.p1 = w.nb / 2;
+    g.A = M; g.B = W; g.C = V;
+    int rc = launch_gemm<T, OP_TRTRI_T, 64>(st, g, w.nb / 2, w.q);
+    if (rc) return rc;
+    g.A = W; g.B = V; g.C = W;
+    rc = launch_gemm<T, OP_TRTRI_W, 64>(st, g, w.nb / 2, w.q);
+    if (rc) return rc;
+    const int nb2 = w.nb / 2;
+    g.nb = nb2;
+    for (int mb = 1; mb < nb2; mb *= 2) {
+        const int pairs = (nb2 + 2 * mb - 1) / (2 * mb);
+        g.p0 = mb; g.p1 = pairs;
         g.A = M; g.B = W; g.C = V;
-        int rc = launch_gemm<T, OP_TRTRI_T>(st, g, pairs * mb * mb, w.q);
+        rc = launch_gemm<T, OP_TRTRI_T, 128>(st, g, pairs * mb * mb, w.q);
         if (rc) return rc;
         g.A = W; g.B = V; g.C = W;
-        rc = launch_gemm<T, OP_TRTRI_W>(st, g, pairs * mb * mb, w.q);
+        rc = launch_gemm<T, OP_TRTRI_W, 128>(st, g, pairs * mb * mb, w.q);
         if (rc) return rc;
     }
     return 0;
@@ -797,9 +931,10 @@ int do_trtri(hipStream_t st, const Ws& w) {
 template <typename T>
 int do_lauum(hipStream_t st, const Ws& w) {
     GemmArgs g;
-    g.sA = g.sB = g.sC = w.mat; g.ldA = g.ldB = g.ldC = w.npad; g.nb = w.nb; g.p0 = g.p1 = 0;
+    const int nb2 = w.nb / 2;
+    g.sA = g.sB = g.sC = w.mat; g.ldA = g.ldB = g.ldC = w.npad; g.nb = nb2; g.p0 = g.p1 = g.p2 = g.p3 = 0;
     g.A = (T*)(w.base + w.off_W); g.B = g.A; g.C = (T*)(w.base + w.off_V);
-    return launch_gemm<T, OP_LAUUM>(st, g, w.ntile_lower, w.q);
+    return launch_gemm<T, OP_LAUUM, 128>(st, g, nb2 * (nb2 + 1) / 2, w.q);
 }
 
 template <typename T>
@@ -807,6 +942,95 @@ int do_potri(hipStream_t st, const Ws& w) {
     int rc = do_trtri<T>(st, w);
     if (rc) return rc;
     return do_lauum<T>(st, w);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Component groups on internal streams.  The Cholesky and the triangular inverse are chains of short,
+// dependent launches (64 diagonal blocks in sequence, shrinking trailing updates, small inverse levels): one
+// chain cannot fill 256 CUs.  The components are independent, so they are split into up to `g_groups` groups,
+// each chain on its own stream; the hardware overlaps the diagonal block of one group with the trailing updates
+// of another and fills the tail of one launch with the head of the next.  The big uniform launches (build,
+// A^-1 = W^T W, symv, gradient contraction) stay single launches over all components on the caller's stream.
+// Streams/events are created once per device and kept (lcgp_shutdown() releases them).
+// ---------------------------------------------------------------------------------------------------
+constexpr int MAX_GROUPS = 8;
+int g_groups = 1;                       // lcgp_set_tuning key 1 (measured: > 2 groups run slower)
+struct StreamPool {
+    bool ready = false;
+    hipStream_t s[MAX_GROUPS];
+    hipEvent_t fork, join[MAX_GROUPS];
+};
+StreamPool g_pool[16];
+
+int pool_get(StreamPool*& out) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return fail("hipGetDevice", e);
+    if (dev < 0 || dev >= 16) return bad("device index out of range");
+    StreamPool& p = g_pool[dev];
+    if (!p.ready) {
+        for (int i = 0; i < MAX_GROUPS; ++i) {
+            e = hipStreamCreateWithFlags(&p.s[i], hipStreamNonBlocking);
+            if (e != hipSuccess) return fail("hipStreamCreateWithFlags", e);
+            e = hipEventCreateWithFlags(&p.join[i], hipEventDisableTiming);
+            if (e != hipSuccess) return fail("hipEventCreateWithFlags", e);
+        }
+        e = hipEventCreateWithFlags(&p.fork, hipEventDisableTiming);
+        if (e != hipSuccess) return fail("hipEventCreateWithFlags", e);
+        p.ready = true;
+    }
+    out = &p;
+    return 0;
+}
+
+// view of the workspace restricted to components [k0, k0 + kq)
+inline Ws sub_ws(const Ws& w, int k0, int kq) {
+    Ws v = w;
+    v.q = kq;
+    v.off_M += (size_t)k0 * w.mat * w.esz;
+    v.off_W += (size_t)k0 * w.mat * w.esz;
+    v.off_V += (size_t)k0 * w.mat * w.esz;
+    v.off_b += (size_t)k0 * w.npad * w.esz;
+    v.off_z += (size_t)k0 * w.npad * w.esz;
+    v.off_part += (size_t)k0 * w.ntile_lower * (DMAX + 2) * sizeof(double);
+    v.off_logdet += (size_t)k0 * sizeof(double);
+    v.off_info += (size_t)k0 * sizeof(int);
+    return v;
+}
+
+// A = L L^T and W = L^-1 for all components of w; returns with everything ordered before later work on `st`.
+template <typename T>
+int factor_and_invert_triangle(hipStream_t st, const Ws& w) {
+    const int G = g_groups < 1 ? 1 : (g_groups > MAX_GROUPS ? MAX_GROUPS : g_groups);
+    const int ng = w.q < G ? w.q : G;
+    if (ng <= 1) {
+        int rc = do_potrf<T>(st, w);
+        if (rc) return rc;
+        return do_trtri<T>(st, w);
+    }
+    StreamPool* pool = nullptr;
+    int rc = pool_get(pool);
+    if (rc) return rc;
+    hipError_t e = hipEventRecord(pool->fork, st);
+    if (e != hipSuccess) return fail("hipEventRecord", e);
+    const int base = w.q / ng, extra = w.q % ng;
+    int k0 = 0;
+    for (int g = 0; g < ng; ++g) {
+        const int kq = base + (g < extra ? 1 : 0);
+        const Ws v = sub_ws(w, k0, kq);
+        k0 += kq;
+        e = hipStreamWaitEvent(pool->s[g], pool->fork, 0);
+        if (e != hipSuccess) return fail("hipStreamWaitEvent", e);
+        rc = do_potrf<T>(pool->s[g], v);
+        if (rc) return rc;
+        rc = do_trtri<T>(pool->s[g], v);
+        if (rc) return rc;
+        e = hipEventRecord(pool->join[g], pool->s[g]);
+        if (e != hipSuccess) return fail("hipEventRecord", e);
+        e = hipStreamWaitEvent(st, pool->join[g], 0);
+        if (e != hipSuccess) return fail("hipStreamWaitEvent", e);
+    }
+    return 0;
 }
 
 template <typename T, int DD>
@@ -826,9 +1050,9 @@ int do_nll_grad(hipStream_t st, const Ws& w, const void* x, const void* Y, const
     hipLaunchKernelGGL((bvec_kernel<T>), dim3((w.npad + 255) / 256, w.q), dim3(256), 0, st, b, w.n, w.npad, w.d, w.p,
                        (const T*)Y, theta);
     CHECK_LAUNCH("bvec_kernel");
-    rc = do_potrf<T>(st, w);
+    rc = factor_and_invert_triangle<T>(st, w);
     if (rc) return rc;
-    rc = do_potri<T>(st, w);
+    rc = do_lauum<T>(st, w);
     if (rc) return rc;
     hipLaunchKernelGGL((symv_kernel<T>), dim3(w.nb, w.q), dim3(256), 0, st, (const T*)(w.base + w.off_V), w.mat, w.npad,
                        w.nb, (const T*)b, z);
@@ -843,6 +1067,9 @@ int do_nll_grad(hipStream_t st, const Ws& w, const void* x, const void* Y, const
                        (const T*)Y, (const T*)b, (const T*)z, (const double*)(w.base + w.off_part),
                        (const double*)(w.base + w.off_logdet), (const int*)(w.base + w.off_info), theta, out);
     CHECK_LAUNCH("finalize_kernel");
+    hipLaunchKernelGGL((gsig_kernel<T>), dim3(w.p, w.q), dim3(256), 0, st, w.n, w.npad, w.d, w.p, (const T*)Y, (const T*)b,
+                       (const T*)z, out);
+    CHECK_LAUNCH("gsig_kernel");
     return 0;
 }
 
@@ -869,7 +1096,7 @@ template <typename T>
 int do_predict(hipStream_t st, const Ws& w, const void* x, const void* sr, const double* theta, int n0, const void* x0,
                int same, void* scratch, double* ghat, double* gvar) {
     const int n0pad = round_up(n0, TS);
-    T* X = (T*)scratch;                                   // n0pad x npad : c0k o sr^T (zero padded)
+    T* X = (T*)scratch;  // (w.npad is a multiple of 128)                                   // n0pad x npad : c0k o sr^T (zero padded)
     T* U = X + (size_t)n0pad * w.npad;                    // n0pad x npad : X W^T = (L^-1 X^T)^T
     ThetaArg dummy;
     memset(&dummy, 0, sizeof(dummy));
@@ -881,7 +1108,7 @@ int do_predict(hipStream_t st, const Ws& w, const void* x, const void* sr, const
         CHECK_LAUNCH("cross_kernel");
         GemmArgs g;
         g.A = X; g.B = (const T*)(w.base + w.off_W) + (size_t)k * w.mat; g.C = U;
-        g.sA = g.sB = g.sC = 0; g.ldA = g.ldB = g.ldC = w.npad; g.nb = w.nb; g.p0 = g.p1 = 0;
+        g.sA = g.sB = g.sC = 0; g.ldA = g.ldB = g.ldC = w.npad; g.nb = w.nb; g.p0 = g.p1 = g.p2 = g.p3 = 0;
         int rc = launch_gemm<T, OP_PRED_U>(st, g, (n0pad / TS) * w.nb, 1);
         if (rc) return rc;
         hipLaunchKernelGGL((pred_reduce_kernel<T>), dim3(n0), dim3(64), 0, st, (const T*)X, (const T*)U, w.npad, w.n,
@@ -903,6 +1130,34 @@ int lcgp_version(void) { return LCGP_VERSION; }
 const char* lcgp_last_error(void) { return g_err; }
 int lcgp_theta_width(int d, int p) { return d + 3 + p; }
 int lcgp_out_width(int d, int p) { return d + 5 + p; }
+
+int lcgp_set_tuning(int key, int value) {
+    if (key == 0) {
+        if (value < 1 || value > 64) return bad("outer panel width must be in [1, 64] blocks");
+        g_outer_blocks = value;
+        return 0;
+    }
+    if (key == 1) {
+        if (value < 1 || value > MAX_GROUPS) return bad("component groups must be in [1, 8]");
+        g_groups = value;
+        return 0;
+    }
+    return bad("unknown tuning key");
+}
+
+int lcgp_shutdown(void) {
+    for (int dev = 0; dev < 16; ++dev) {
+        StreamPool& p = g_pool[dev];
+        if (!p.ready) continue;
+        for (int i = 0; i < MAX_GROUPS; ++i) {
+            (void)hipStreamDestroy(p.s[i]);
+            (void)hipEventDestroy(p.join[i]);
+        }
+        (void)hipEventDestroy(p.fork);
+        p.ready = false;
+    }
+    return 0;
+}
 
 int lcgp_workspace_bytes(int dtype, int n, int d, int p, int q_local, size_t* bytes) {
     int rc = check_common(dtype, n, d, p, q_local);

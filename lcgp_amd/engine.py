@@ -95,7 +95,7 @@ class HotPathEngine:
         x0s = np.ascontiguousarray(x0s, np.float64)
         n0 = x0s.shape[0]
         assert x0s.shape[1] == self.d
-        npad = (self.n + 63) // 64 * 64
+        npad = (self.n + 127) // 128 * 128
         n0pad = (n0 + 63) // 64 * 64
         with torch.cuda.device(self.device):
             x0d = torch.as_tensor(x0s).to(self.device, self.tdtype).contiguous()
