@@ -372,12 +372,14 @@ struct GemmArgs {
     int ldA, ldB, ldC;
     int nb;                                     // number of 64-blocks
     int p0, p1, p2, p3;                         // op specific
+    int q;                                      // components in this launch
 };
 
-// one K-stage (KT = 16 k values) of a TM-row operand tile: global -> registers -> LDS [k][m], ld = TM + 16
-template <typename T, int L, int TM>
-__device__ __forceinline__ void load_stage(const T* __restrict__ P, int ld, int ks, T (&reg)[TM / 16], int tid) {
-    constexpr int EPT = TM / 16;
+// one K-stage (KT = 16 k values) of a TM-row operand tile: global -> registers -> LDS [k][m], ld = TM + 16;
+// NT threads move TM * KT elements, EPT = TM * KT / NT consecutive ones each
+template <typename T, int L, int TM, int NT>
+__device__ __forceinline__ void load_stage(const T* __restrict__ P, int ld, int ks, T (&reg)[TM * KT / NT], int tid) {
+    constexpr int EPT = TM * KT / NT;
     if (L == MK) {
         constexpr int TPR = KT / EPT;                       // threads per operand row (a row holds 16 k values)
         const int m = tid / TPR, kk = (tid % TPR) * EPT;
@@ -385,16 +387,17 @@ __device__ __forceinline__ void load_stage(const T* __restrict__ P, int ld, int 
 #pragma unroll
         for (int e = 0; e < EPT; ++e) reg[e] = src[e];
     } else {
-        const int kq = tid >> 4, mm = (tid & 15) * EPT;
+        constexpr int TPK = TM / EPT;                       // threads per k row
+        const int kq = tid / TPK, mm = (tid % TPK) * EPT;
         const T* src = P + (size_t)(ks + kq) * ld + mm;
 #pragma unroll
         for (int e = 0; e < EPT; ++e) reg[e] = src[e];
     }
 }
 
-template <typename T, int L, int TM>
-__device__ __forceinline__ void store_stage(T* __restrict__ S, const T (&reg)[TM / 16], int tid) {
-    constexpr int EPT = TM / 16;
+template <typename T, int L, int TM, int NT>
+__device__ __forceinline__ void store_stage(T* __restrict__ S, const T (&reg)[TM * KT / NT], int tid) {
+    constexpr int EPT = TM * KT / NT;
     constexpr int LD = TM + 16;
     if (L == MK) {
         constexpr int TPR = KT / EPT;
@@ -402,7 +405,8 @@ __device__ __forceinline__ void store_stage(T* __restrict__ S, const T (&reg)[TM
 #pragma unroll
         for (int e = 0; e < EPT; ++e) S[(kk + e) * LD + m] = reg[e];
     } else {
-        const int kq = tid >> 4, mm = (tid & 15) * EPT;
+        constexpr int TPK = TM / EPT;
+        const int kq = tid / TPK, mm = (tid % TPK) * EPT;
 #pragma unroll
         for (int e = 0; e < EPT; ++e) S[kq * LD + mm + e] = reg[e];
     }
@@ -416,34 +420,41 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
     return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
 }
 
-// TM x TM output tile per 256-thread workgroup (TM = 64: 32x32 per wave, 2x2 MFMA accumulators;
-// TM = 128: 64x64 per wave, 4x4 accumulators -- half the operand traffic per flop).  All tile coordinates
-// (g.nb, g.p0..p3) are in units of TM.
-template <typename T, int OP, int TM>
-__global__ __launch_bounds__(256, TM == 128 ? 2 : 4) void tile_gemm(GemmArgs g) {
+// TM x TM output tile per workgroup of NW waves arranged (NW/2) x 2:
+//   TM = 64,  NW = 4: 32x32 per wave (2x2 MFMA accumulators), 4 workgroups per CU
+//   TM = 128, NW = 8: 32x64 per wave (2x4 accumulators), 2 workgroups per CU = 4 waves per SIMD, half the
+//                     operand traffic per flop of the 64-tile
+// All tile coordinates (g.nb, g.p0..p3) are in units of TM.
+template <typename T, int OP, int TM, int NW>
+__global__ __launch_bounds__(NW * 64, TM == 128 ? (NW == 8 ? 4 : 2) : 4) void tile_gemm(GemmArgs g) {
     constexpr int LA = (OP == OP_LAUUM) ? KM : MK;
     constexpr int LB = (OP == OP_TRTRI_T || OP == OP_TRTRI_W || OP == OP_LAUUM) ? KM : MK;
+    constexpr int NT = NW * 64;
     constexpr int LD = TM + 16;     // = 16 (mod 32): the two k rows a 32-lane group reads hit disjoint banks
-    constexpr int WT = TM / 2;      // rows/cols of the per-wave sub-tile
-    constexpr int MI = WT / 16;     // MFMA tiles per wave per dimension
-    constexpr int EPT = TM / 16;
+    constexpr int WTM = TM / (NW / 2), WTN = TM / 2;   // per-wave sub-tile
+    constexpr int MIM = WTM / 16, MIN = WTN / 16;      // MFMA tiles per wave
+    constexpr int EPT = TM * KT / NT;
     __shared__ T As[2][KT * LD];
     __shared__ T Bs[2][KT * LD];
 
-    const int k = blockIdx.y;
+    // 1-D grid over (tile, component) with the component as the FAST index: tiles are enumerated heaviest first,
+    // so the heaviest tiles of every component start at once instead of component by component
+    const int k = blockIdx.x % g.q;
+    const int bid = blockIdx.x / g.q;
+    const int ntile = gridDim.x / g.q;
     const T* Ab = (const T*)g.A + (size_t)k * g.sA;
     const T* Bb = (const T*)g.B + (size_t)k * g.sB;
     T* Cb = (T*)g.C + (size_t)k * g.sC;
 
     // ---- per-op tile decode: A0/B0 = first operand tiles, dA/dB = pointer step per kt, nkt, C tile ----
     const T* A0; const T* B0; T* Ct;
-    size_t dA, dB;
+    ptrdiff_t dA, dB;           // signed: some ops walk their k tiles downwards (see below)
     int nkt;
     double alpha = 1.0;
     bool accumulate = false;
     if constexpr (OP == OP_TRMM_PANEL) {
         // M[r, j] = M[r, j] * W[j, j]^T for r = j+1+bid      (L21 = A21 L11^-T)
-        const int j = g.p0, r = j + 1 + blockIdx.x;
+        const int j = g.p0, r = j + 1 + bid;
         A0 = Ab + (size_t)r * TM * g.ldA + (size_t)j * TM; dA = 0;
         B0 = Bb + (size_t)j * TM * g.ldB + (size_t)j * TM; dB = 0;
         nkt = 1;
@@ -451,7 +462,7 @@ __global__ __launch_bounds__(256, TM == 128 ? 2 : 4) void tile_gemm(GemmArgs g) 
     } else if constexpr (OP == OP_SYRK) {
         // M[r, c] -= sum_{kt in [p0, p1)} M[r, kt] M[c, kt]^T over the tiles c in [p2, p3), r in [c, nb)
         // (p3 == nb: the whole trailing triangle; p3 < nb: the rest of the current panel), column-major
-        int t = xcd_remap(blockIdx.x, gridDim.x), c = g.p2;
+        int t = bid, c = g.p2;
         while (t >= g.nb - c) { t -= g.nb - c; ++c; }
         const int r = c + t;
         A0 = Ab + (size_t)r * TM * g.ldA + (size_t)g.p0 * TM; dA = TM;
@@ -465,7 +476,7 @@ __global__ __launch_bounds__(256, TM == 128 ? 2 : 4) void tile_gemm(GemmArgs g) 
         // fastest one) so that the long tiles start early and the short ones fill the tail.
         const int mb = g.p0;
         const int npair = g.p1;
-        const int pr = blockIdx.x % npair, rem = blockIdx.x / npair;
+        const int pr = bid % npair, rem = bid / npair;
         int rl, cl;
         if constexpr (OP == OP_TRTRI_T) { cl = rem / mb; rl = rem - cl * mb; }
         else { rl = mb - 1 - rem / mb; cl = rem % mb; }
@@ -473,13 +484,15 @@ __global__ __launch_bounds__(256, TM == 128 ? 2 : 4) void tile_gemm(GemmArgs g) 
         if (R0 + rl >= g.nb) return;
         if constexpr (OP == OP_TRTRI_T) {
             // T[rl, cl] = sum_{kt = cl}^{mb-1} L21[rl, kt] W11[kt, cl]          (A from M, B from W, C into V)
-            A0 = Ab + (size_t)(R0 + rl) * TM * g.ldA + (size_t)(C0 + cl) * TM; dA = TM;
-            B0 = Bb + (size_t)(C0 + cl) * TM * g.ldB + (size_t)(C0 + cl) * TM; dB = (size_t)TM * g.ldB;
+            // walked from kt = mb-1 DOWN to cl: all tiles of the launch start on the same block row of W11 and
+            // the same block column of L21 and stay in step, so the per-XCD L2 serves the re-reads
+            A0 = Ab + (size_t)(R0 + rl) * TM * g.ldA + (size_t)(C0 + mb - 1) * TM; dA = -(ptrdiff_t)TM;
+            B0 = Bb + (size_t)(C0 + mb - 1) * TM * g.ldB + (size_t)(C0 + cl) * TM; dB = -(ptrdiff_t)TM * g.ldB;
             nkt = mb - cl;
         } else {
             // W21[rl, cl] = - sum_{kt = 0}^{rl} W22[rl, kt] T[kt, cl]            (A from W, B from V, C into W)
             A0 = Ab + (size_t)(R0 + rl) * TM * g.ldA + (size_t)R0 * TM; dA = TM;
-            B0 = Bb + (size_t)R0 * TM * g.ldB + (size_t)(C0 + cl) * TM; dB = (size_t)TM * g.ldB;
+            B0 = Bb + (size_t)R0 * TM * g.ldB + (size_t)(C0 + cl) * TM; dB = (ptrdiff_t)TM * g.ldB;
             nkt = rl + 1;
             alpha = -1.0;
         }
@@ -487,14 +500,15 @@ __global__ __launch_bounds__(256, TM == 128 ? 2 : 4) void tile_gemm(GemmArgs g) 
     } else if constexpr (OP == OP_LAUUM) {
         // V[r, c] = sum_{kt = r}^{nb-1} W[kt, r]^T W[kt, c]
         int r, c;
-        tri_decode(blockIdx.x, r, c);   // ascending r = longest k loops first; round-robin XCD dealing balances them
-        A0 = Ab + (size_t)r * TM * g.ldA + (size_t)r * TM; dA = (size_t)TM * g.ldA;
-        B0 = Bb + (size_t)r * TM * g.ldB + (size_t)c * TM; dB = (size_t)TM * g.ldB;
+        tri_decode(bid, r, c);   // ascending r = longest k loops first
+        // k tiles walked from nb-1 DOWN to r: every tile starts on the last block row of W and they stay in step
+        A0 = Ab + (size_t)(g.nb - 1) * TM * g.ldA + (size_t)r * TM; dA = -(ptrdiff_t)TM * g.ldA;
+        B0 = Bb + (size_t)(g.nb - 1) * TM * g.ldB + (size_t)c * TM; dB = -(ptrdiff_t)TM * g.ldB;
         nkt = g.nb - r;
         Ct = Cb + (size_t)r * TM * g.ldC + (size_t)c * TM;
     } else {
         // OP_PRED_U: U[m, r] = sum_{kt = 0}^{r} X[m, kt] W[r, kt]^T    (X = scaled cross covariance, n0pad x npad)
-        const int r = blockIdx.x % g.nb, m = blockIdx.x / g.nb;
+        const int r = bid % g.nb, m = bid / g.nb;
         A0 = Ab + (size_t)m * TM * g.ldA; dA = TM;
         B0 = Bb + (size_t)r * TM * g.ldB; dB = TM;
         nkt = r + 1;
@@ -504,16 +518,16 @@ __global__ __launch_bounds__(256, TM == 128 ? 2 : 4) void tile_gemm(GemmArgs g) 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
-    const int wm0 = (wave >> 1) * WT, wn0 = (wave & 1) * WT;
+    const int wm0 = (wave >> 1) * WTM, wn0 = (wave & 1) * WTN;
     typedef typename Mfma<T>::acc_t acc_t;
-    acc_t acc[MI][MI];
+    acc_t acc[MIM][MIN];
     // C -= A B^T: the accumulators start from the C tile (its load overlaps the first operand loads) and the A
     // fragments are negated, so the epilogue is stores only
     constexpr bool PRELOAD_C = (OP == OP_SYRK);
 #pragma unroll
-    for (int i = 0; i < MI; ++i)
+    for (int i = 0; i < MIM; ++i)
 #pragma unroll
-        for (int j = 0; j < MI; ++j)
+        for (int j = 0; j < MIN; ++j)
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 if constexpr (PRELOAD_C) {
@@ -528,40 +542,42 @@ __global__ __launch_bounds__(256, TM == 128 ? 2 : 4) void tile_gemm(GemmArgs g) 
     constexpr int SPT = TM / KT;   // stages per k tile
     const int nst = nkt * SPT;
     T ra[EPT], rb[EPT];
-    load_stage<T, LA, TM>(A0, g.ldA, 0, ra, tid);
-    load_stage<T, LB, TM>(B0, g.ldB, 0, rb, tid);
+    load_stage<T, LA, TM, NT>(A0, g.ldA, 0, ra, tid);
+    load_stage<T, LB, TM, NT>(B0, g.ldB, 0, rb, tid);
     for (int s = 0; s < nst; ++s) {
         const int buf = s & 1;
-        store_stage<T, LA, TM>(As[buf], ra, tid);
-        store_stage<T, LB, TM>(Bs[buf], rb, tid);
+        store_stage<T, LA, TM, NT>(As[buf], ra, tid);
+        store_stage<T, LB, TM, NT>(Bs[buf], rb, tid);
         __syncthreads();
         if (s + 1 < nst) {
             const int kt = (s + 1) / SPT, ks = ((s + 1) % SPT) * KT;
-            load_stage<T, LA, TM>(A0 + (size_t)kt * dA, g.ldA, ks, ra, tid);
-            load_stage<T, LB, TM>(B0 + (size_t)kt * dB, g.ldB, ks, rb, tid);
+            load_stage<T, LA, TM, NT>(A0 + (ptrdiff_t)kt * dA, g.ldA, ks, ra, tid);
+            load_stage<T, LB, TM, NT>(B0 + (ptrdiff_t)kt * dB, g.ldB, ks, rb, tid);
         }
         const T* as = As[buf];
         const T* bs = Bs[buf];
 #pragma unroll
         for (int kk = 0; kk < KT / 4; ++kk) {
             const int krow = (kk * 4 + (lane >> 4)) * LD;
-            T af[MI], bf[MI];
+            T af[MIM], bf[MIN];
 #pragma unroll
-            for (int i = 0; i < MI; ++i) {
-                af[i] = PRELOAD_C ? -as[krow + wm0 + i * 16 + (lane & 15)] : as[krow + wm0 + i * 16 + (lane & 15)];
-                bf[i] = bs[krow + wn0 + i * 16 + (lane & 15)];
+            for (int i = 0; i < MIM; ++i) {
+                const T v = as[krow + wm0 + i * 16 + (lane & 15)];
+                af[i] = PRELOAD_C ? -v : v;
             }
 #pragma unroll
-            for (int i = 0; i < MI; ++i)
+            for (int j = 0; j < MIN; ++j) bf[j] = bs[krow + wn0 + j * 16 + (lane & 15)];
 #pragma unroll
-                for (int j = 0; j < MI; ++j) acc[i][j] = Mfma<T>::run(af[i], bf[j], acc[i][j]);
+            for (int i = 0; i < MIM; ++i)
+#pragma unroll
+                for (int j = 0; j < MIN; ++j) acc[i][j] = Mfma<T>::run(af[i], bf[j], acc[i][j]);
         }
     }
     // (the panel TRMM overwrites its own A tile: all of it went through LDS before the last barrier)
 #pragma unroll
-    for (int mi = 0; mi < MI; ++mi)
+    for (int mi = 0; mi < MIM; ++mi)
 #pragma unroll
-        for (int ni = 0; ni < MI; ++ni)
+        for (int ni = 0; ni < MIN; ++ni)
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const int row = wm0 + mi * 16 + Mfma<T>::row(lane, e);
@@ -841,7 +857,10 @@ int do_build(hipStream_t st, const Ws& w, const void* x, const void* sr, const d
 template <typename T, int OP, int TM = TS>
 int launch_gemm(hipStream_t st, const GemmArgs& g, int ntiles, int q) {
     if (ntiles <= 0) return 0;
-    hipLaunchKernelGGL((tile_gemm<T, OP, TM>), dim3(ntiles, q), dim3(256), 0, st, g);
+    constexpr int NW = TM == 128 ? 8 : 4;
+    GemmArgs h = g;
+    h.q = q;
+    hipLaunchKernelGGL((tile_gemm<T, OP, TM, NW>), dim3((unsigned)ntiles * q), dim3(NW * 64), 0, st, h);
     CHECK_LAUNCH("tile_gemm");
     return 0;
 }
