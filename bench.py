@@ -157,6 +157,8 @@ def main():
     from lcgp_amd import LCGP, synth, _hip
     if os.environ.get('LCGP_OB'):
         _hip.check(_hip.load().lcgp_set_tuning(0, int(os.environ['LCGP_OB'])), 'lcgp_set_tuning')
+    if os.environ.get('LCGP_DBG'):
+        _hip.check(_hip.load().lcgp_set_tuning(2, int(os.environ['LCGP_DBG'])), 'lcgp_set_tuning')
     if os.environ.get('LCGP_GROUPS'):
         _hip.check(_hip.load().lcgp_set_tuning(1, int(os.environ['LCGP_GROUPS'])), 'lcgp_set_tuning')
     over = {} if args.n is None else dict(n=args.n)

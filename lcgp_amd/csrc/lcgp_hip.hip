@@ -266,7 +266,7 @@ __device__ __forceinline__ void leaf_pivot_group(double (&r)[16], double (*colbu
 
 template <typename T>
 __global__ __launch_bounds__(256) void leaf_kernel(T* __restrict__ M, T* __restrict__ W, size_t mat, int npad, int jb,
-                                                   double* __restrict__ logdet, int* __restrict__ info) {
+                                                   double* __restrict__ logdet, int* __restrict__ info, int dbg) {
     __shared__ double colbuf[2][TS];
     __shared__ double dinv[TS];
     __shared__ double a[TS][TS + 1];
@@ -286,10 +286,12 @@ __global__ __launch_bounds__(256) void leaf_kernel(T* __restrict__ M, T* __restr
     }
     double piv = 1.0;
     int first_bad = 0;
-    leaf_pivot_group<0>(r, colbuf, 0, cj, rg, piv, first_bad, jb);
-    leaf_pivot_group<4>(r, colbuf, 16, cj, rg, piv, first_bad, jb);
-    leaf_pivot_group<8>(r, colbuf, 32, cj, rg, piv, first_bad, jb);
-    leaf_pivot_group<12>(r, colbuf, 48, cj, rg, piv, first_bad, jb);
+    if (!(dbg & 1)) {
+        leaf_pivot_group<0>(r, colbuf, 0, cj, rg, piv, first_bad, jb);
+        leaf_pivot_group<4>(r, colbuf, 16, cj, rg, piv, first_bad, jb);
+        leaf_pivot_group<8>(r, colbuf, 32, cj, rg, piv, first_bad, jb);
+        leaf_pivot_group<12>(r, colbuf, 48, cj, rg, piv, first_bad, jb);
+    }
     // column cj is final up to the scaling by 1/sqrt(pivot)
     const double rs = 1.0 / sqrt(piv);
 #pragma unroll
@@ -310,6 +312,7 @@ __global__ __launch_bounds__(256) void leaf_kernel(T* __restrict__ M, T* __restr
         }
     }
     __syncthreads();
+    if (dbg & 2) return;
     // ---- inverse of the 64x64 lower-triangular block, blocked by 16 ----
     // (a) the four 16x16 diagonal blocks: thread = one column, kept in registers (solve L w = e_cl)
     if (tid < TS) {
@@ -866,6 +869,7 @@ int launch_gemm(hipStream_t st, const GemmArgs& g, int ntiles, int q) {
 }
 
 int g_outer_blocks = 4;   // width of the outer Cholesky panel in 64-blocks (lcgp_set_tuning key 0)
+int g_debug_mask = 0;     // timing experiments only (lcgp_set_tuning key 2): 1 = skip pivots, 2 = skip inverse
 
 inline int trapezoid_tiles(int nb, int c_lo, int c_hi) {
     return (c_hi - c_lo) * nb - (c_lo + c_hi - 1) * (c_hi - c_lo) / 2;
@@ -888,7 +892,8 @@ int do_potrf(hipStream_t st, const Ws& w) {
     for (int J = 0; J < w.nb; J += ob) {
         const int pe = J + ob < w.nb ? J + ob : w.nb;
         for (int c = J; c < pe; ++c) {
-            hipLaunchKernelGGL((leaf_kernel<T>), dim3(w.q), dim3(256), 0, st, M, W, w.mat, w.npad, c, logdet, info);
+            hipLaunchKernelGGL((leaf_kernel<T>), dim3(w.q), dim3(256), 0, st, M, W, w.mat, w.npad, c, logdet, info,
+                               g_debug_mask);
             CHECK_LAUNCH("leaf_kernel");
             if (c + 1 >= w.nb) break;
             g.A = M; g.B = W; g.C = M; g.p0 = c; g.p1 = g.p2 = g.p3 = 0;
@@ -1154,6 +1159,10 @@ int lcgp_set_tuning(int key, int value) {
     if (key == 0) {
         if (value < 1 || value > 64) return bad("outer panel width must be in [1, 64] blocks");
         g_outer_blocks = value;
+        return 0;
+    }
+    if (key == 2) {
+        g_debug_mask = value;
         return 0;
     }
     if (key == 1) {
