@@ -121,49 +121,58 @@ template <typename T>
 __global__ __launch_bounds__(256) void build_kernel(T* __restrict__ M, size_t mat, int n, int npad, int d, int p,
                                                     const T* __restrict__ x, const T* __restrict__ sr,
                                                     const double* __restrict__ theta) {
-    __shared__ double xr[TS][DMAX + 1];
-    __shared__ double xc[TS][DMAX + 1];
-    __shared__ double srr[TS], src[TS];
+    // arithmetic in the storage type: the float32 variant is the HBM-bound regime (one float exp per element)
+    __shared__ T xr[TS][DMAX + 1];
+    __shared__ T xc[TS][DMAX + 1];
+    __shared__ T srr[TS], src[TS];
     const int k = blockIdx.y;
     int r, c;
     tri_decode(blockIdx.x, r, c);
     const double* th = th_row(theta, d, p, k);
     const double scale = th[d], nug = th[d + 1], D = th[d + 2];
     const double nt = nug / (1.0 + nug);
+    const T c_off = (T)(D * scale * (1.0 - nt));        // multiplies C0
+    const T c_diag = (T)(1.0 + D * scale * nt);         // extra term on the diagonal (times sr_i^2)
     const int tid = threadIdx.x;
     for (int e = tid; e < TS * d; e += 256) {
         int i = e / d, j = e - i * d;
         int gi = r * TS + i, gj = c * TS + i;
-        xr[i][j] = gi < n ? (double)x[(size_t)gi * d + j] / th[j] : 0.0;
-        xc[i][j] = gj < n ? (double)x[(size_t)gj * d + j] / th[j] : 0.0;
+        xr[i][j] = gi < n ? (T)((double)x[(size_t)gi * d + j] / th[j]) : (T)0;
+        xc[i][j] = gj < n ? (T)((double)x[(size_t)gj * d + j] / th[j]) : (T)0;
     }
     if (tid < TS) {
         int gi = r * TS + tid, gj = c * TS + tid;
-        srr[tid] = (sr && gi < n) ? (double)sr[gi] : 1.0;
-        src[tid] = (sr && gj < n) ? (double)sr[gj] : 1.0;
+        srr[tid] = (sr && gi < n) ? sr[gi] : (T)1;
+        src[tid] = (sr && gj < n) ? sr[gj] : (T)1;
     }
     __syncthreads();
     T* Mk = M + (size_t)k * mat;
     const int j = tid & 63;
     const int gj = c * TS + j;
+    T xcj[DMAX];
+#pragma unroll
+    for (int jj = 0; jj < DMAX; ++jj) xcj[jj] = jj < d ? xc[j][jj] : (T)0;
     for (int m = 0; m < 16; ++m) {
         const int i = (tid >> 6) * 16 + m;
         const int gi = r * TS + i;
-        double v;
+        T v;
         if (gi < n && gj < n) {
-            double poly = 1.0, ssum = 0.0;
-            for (int jj = 0; jj < d; ++jj) {
-                double s = fabs(xr[i][jj] - xc[j][jj]);
-                poly *= 1.0 + s;
-                ssum -= s;
+            T poly = 1, ssum = 0;
+#pragma unroll
+            for (int jj = 0; jj < DMAX; ++jj) {
+                if (jj < d) {
+                    T s = fabs(xr[i][jj] - xcj[jj]);
+                    poly *= (T)1 + s;
+                    ssum -= s;
+                }
             }
-            double c0 = poly * exp(ssum);
-            double dl = gi == gj ? 1.0 : 0.0;
-            v = dl + D * srr[i] * src[j] * scale * ((1.0 - nt) * c0 + nt * dl);
+            T c0 = poly * exp(ssum);
+            v = srr[i] * src[j] * c_off * c0;
+            if (gi == gj) v += (T)1 + (c_diag - (T)1) * srr[i] * src[j];
         } else {
-            v = gi == gj ? 1.0 : 0.0;
+            v = gi == gj ? (T)1 : (T)0;
         }
-        Mk[(size_t)gi * npad + gj] = (T)v;
+        Mk[(size_t)gi * npad + gj] = v;
     }
 }
 

@@ -63,3 +63,16 @@ def gather_rows(local_rows, q: int, group=None, device=None):
         return full
     # disjoint rows: a sum is a gather
     return all_reduce_sum(full.reshape(-1), group, device).reshape(q, m)
+
+
+def broadcast_array(arr, src=0, group=None, device=None):
+    """Every rank returns rank `src`'s float64 array (used so that all ranks share ONE SVD basis)."""
+    if not is_distributed(group):
+        return np.asarray(arr, np.float64)
+    import torch
+    dist = _dist()
+    t = torch.as_tensor(np.ascontiguousarray(arr, np.float64)).clone()
+    if dist.get_backend(group) == "nccl":
+        t = t.to(device if device is not None else torch.device("cuda", torch.cuda.current_device()))
+    dist.broadcast(t, src=dist.get_global_rank(group, src) if group is not None else src, group=group)
+    return t.cpu().numpy()

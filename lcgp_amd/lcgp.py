@@ -103,6 +103,12 @@ class LCGP:
             self.y, self.ymean, self.ystd, _ = self.init_standard_y(self.y)
 
         self.g, self.phi, self.diag_D, self.q = self.init_phi(var_threshold=var_threshold)
+        if _dist.is_distributed(self._group):
+            # the SVD basis is only defined up to column signs: all ranks must use rank 0's
+            dev = torch.device(device) if device is not None else None
+            self.phi = _t(_dist.broadcast_array(_np(self.phi), 0, self._group, dev))
+            self.g = _t(_dist.broadcast_array(_np(self.g), 0, self._group, dev))
+            self.diag_D = _t(_dist.broadcast_array(_np(self.diag_D), 0, self._group, dev))
 
         if diag_error_structure is None:
             self.diag_error_structure = [1] * int(self.p)
