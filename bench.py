@@ -157,6 +157,10 @@ def main():
     from lcgp_amd import LCGP, synth, _hip
     if os.environ.get('LCGP_OB'):
         _hip.check(_hip.load().lcgp_set_tuning(0, int(os.environ['LCGP_OB'])), 'lcgp_set_tuning')
+    if os.environ.get('LCGP_PRIO'):
+        _hip.check(_hip.load().lcgp_set_tuning(4, int(os.environ['LCGP_PRIO'])), 'lcgp_set_tuning')
+    if os.environ.get('LCGP_LA'):
+        _hip.check(_hip.load().lcgp_set_tuning(3, int(os.environ['LCGP_LA'])), 'lcgp_set_tuning')
     if os.environ.get('LCGP_DBG'):
         _hip.check(_hip.load().lcgp_set_tuning(2, int(os.environ['LCGP_DBG'])), 'lcgp_set_tuning')
     if os.environ.get('LCGP_GROUPS'):

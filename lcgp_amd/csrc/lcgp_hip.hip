@@ -280,7 +280,8 @@ __global__ __launch_bounds__(256) void leaf_kernel(T* __restrict__ M, T* __restr
     __shared__ double dinv[TS];
     __shared__ double a[TS][TS + 1];
     __shared__ double w[TS][TS + 1];
-    __shared__ double t[TS][TS + 1];
+    __shared__ double t[3][16][17];   // T_ab of the current block distance only (keeps the LDS footprint < 80 KB so
+                                      // that this kernel can share a CU with a 128x128 tile workgroup)
     const int k = blockIdx.x;
     const int tid = threadIdx.x;
     T* Mb = M + (size_t)k * mat + (size_t)jb * TS * npad + (size_t)jb * TS;
@@ -348,13 +349,13 @@ __global__ __launch_bounds__(256) void leaf_kernel(T* __restrict__ M, T* __restr
             for (int mb = bb; mb < ab; ++mb)
 #pragma unroll
                 for (int m = 0; m < 16; ++m) sacc = fma(a[ab * 16 + ei][mb * 16 + m], w[mb * 16 + m][bb * 16 + ej], sacc);
-            t[ab * 16 + ei][bb * 16 + ej] = sacc;
+            t[bb][ei][ej] = sacc;
         }
         __syncthreads();
         for (int bb = 0; bb + dist < 4; ++bb) {
             const int ab = bb + dist;
             double sacc = 0.0;
-            for (int m = 0; m <= ei; ++m) sacc = fma(w[ab * 16 + ei][ab * 16 + m], t[ab * 16 + m][bb * 16 + ej], sacc);
+            for (int m = 0; m <= ei; ++m) sacc = fma(w[ab * 16 + ei][ab * 16 + m], t[bb][m][ej], sacc);
             w[ab * 16 + ei][bb * 16 + ej] = -sacc;
         }
         __syncthreads();
@@ -877,6 +878,57 @@ int launch_gemm(hipStream_t st, const GemmArgs& g, int ntiles, int q) {
     return 0;
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Component groups on internal streams.  The Cholesky and the triangular inverse are chains of short,
+// dependent launches (64 diagonal blocks in sequence, shrinking trailing updates, small inverse levels): one
+// chain cannot fill 256 CUs.  The components are independent, so they are split into up to `g_groups` groups,
+// each chain on its own stream; the hardware overlaps the diagonal block of one group with the trailing updates
+// of another and fills the tail of one launch with the head of the next.  The big uniform launches (build,
+// A^-1 = W^T W, symv, gradient contraction) stay single launches over all components on the caller's stream.
+// Streams/events are created once per device and kept (lcgp_shutdown() releases them).
+// ---------------------------------------------------------------------------------------------------
+extern int g_chain_prio;
+constexpr int MAX_GROUPS = 8;
+int g_groups = 1;                       // lcgp_set_tuning key 1 (measured: > 2 groups run slower, see DESIGN.md)
+struct StreamPool {
+    bool ready = false;
+    hipStream_t s[MAX_GROUPS];
+    hipEvent_t fork, join[MAX_GROUPS];
+    hipStream_t chain;                 // high-priority stream of the look-ahead Cholesky (panel chain)
+    hipEvent_t ev_panel, ev_next, ev_fork2, ev_join2;
+};
+StreamPool g_pool[16];
+
+int pool_get(StreamPool*& out) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return fail("hipGetDevice", e);
+    if (dev < 0 || dev >= 16) return bad("device index out of range");
+    StreamPool& p = g_pool[dev];
+    if (!p.ready) {
+        for (int i = 0; i < MAX_GROUPS; ++i) {
+            e = hipStreamCreateWithFlags(&p.s[i], hipStreamNonBlocking);
+            if (e != hipSuccess) return fail("hipStreamCreateWithFlags", e);
+            e = hipEventCreateWithFlags(&p.join[i], hipEventDisableTiming);
+            if (e != hipSuccess) return fail("hipEventCreateWithFlags", e);
+        }
+        e = hipEventCreateWithFlags(&p.fork, hipEventDisableTiming);
+        if (e != hipSuccess) return fail("hipEventCreateWithFlags", e);
+        int lo = 0, hi = 0;
+        (void)hipDeviceGetStreamPriorityRange(&lo, &hi);      // hi = numerically lowest = highest priority
+        e = hipStreamCreateWithPriority(&p.chain, hipStreamNonBlocking, g_chain_prio ? hi : lo);
+        if (e != hipSuccess) return fail("hipStreamCreateWithPriority", e);
+        hipEvent_t* evs[4] = {&p.ev_panel, &p.ev_next, &p.ev_fork2, &p.ev_join2};
+        for (int i = 0; i < 4; ++i) {
+            e = hipEventCreateWithFlags(evs[i], hipEventDisableTiming);
+            if (e != hipSuccess) return fail("hipEventCreateWithFlags", e);
+        }
+        p.ready = true;
+    }
+    out = &p;
+    return 0;
+}
+
 int g_outer_blocks = 4;   // width of the outer Cholesky panel in 64-blocks (lcgp_set_tuning key 0)
 int g_debug_mask = 0;     // timing experiments only (lcgp_set_tuning key 2): 1 = skip pivots, 2 = skip inverse
 
@@ -887,47 +939,141 @@ inline int trapezoid_tiles(int nb, int c_lo, int c_hi) {
 // Two-level right-looking Cholesky.  Outer panels of `g_outer_blocks` 64-blocks: inside a panel every 64-column
 // step is  diagonal block -> panel TRMM -> rank-64 update of the REST OF THE PANEL only;  the trailing matrix
 // is touched once per outer panel with K = 64 * g_outer_blocks (read-modify-write traffic / g_outer_blocks).
+int g_chain_prio = 0;     // lcgp_set_tuning key 4: 1 = create the chain stream with the highest priority (before first use)
+int g_lookahead = 0;      // lcgp_set_tuning key 3: 1 = panel chain on its own stream ahead of the trailing update.
+                          // OFF by default: measured on MI355X / ROCm 7.2, as soon as one HIP stream waits on another
+                          // (barrier packet) every kernel boundary on the running stream costs 20-40 us, so the
+                          // overlapped schedule runs 2.2x SLOWER (potrf 6.6 -> 14.4 ms at n=4096, q=8); see DESIGN.md
+
+#define HIPCHECK(call, what)                                \
+    do {                                                    \
+        hipError_t e__ = (call);                            \
+        if (e__ != hipSuccess) return fail(what, e__);      \
+    } while (0)
+
+// one outer panel [J, pe): per 64-column step  diagonal block -> panel TRMM -> rank-64 update of the rest of the panel
 template <typename T>
-int do_potrf(hipStream_t st, const Ws& w) {
+int potrf_panel(hipStream_t st, const Ws& w, int J, int pe) {
     T* M = (T*)(w.base + w.off_M);
     T* W = (T*)(w.base + w.off_W);
     double* logdet = (double*)(w.base + w.off_logdet);
     int* info = (int*)(w.base + w.off_info);
-    hipLaunchKernelGGL(zero_stats_kernel, dim3((w.q + 63) / 64), dim3(64), 0, st, logdet, info, w.q);
-    CHECK_LAUNCH("zero_stats");
     GemmArgs g;
     g.sA = g.sB = g.sC = w.mat; g.ldA = g.ldB = g.ldC = w.npad; g.nb = w.nb;
-    const int ob = g_outer_blocks < 1 ? 1 : g_outer_blocks;
-    for (int J = 0; J < w.nb; J += ob) {
-        const int pe = J + ob < w.nb ? J + ob : w.nb;
-        for (int c = J; c < pe; ++c) {
-            hipLaunchKernelGGL((leaf_kernel<T>), dim3(w.q), dim3(256), 0, st, M, W, w.mat, w.npad, c, logdet, info,
-                               g_debug_mask);
-            CHECK_LAUNCH("leaf_kernel");
-            if (c + 1 >= w.nb) break;
-            g.A = M; g.B = W; g.C = M; g.p0 = c; g.p1 = g.p2 = g.p3 = 0;
-            int rc = launch_gemm<T, OP_TRMM_PANEL>(st, g, w.nb - 1 - c, w.q);
-            if (rc) return rc;
-            if (c + 1 < pe) {
-                g.A = M; g.B = M; g.C = M; g.p0 = c; g.p1 = c + 1; g.p2 = c + 1; g.p3 = pe;
-                rc = launch_gemm<T, OP_SYRK>(st, g, trapezoid_tiles(w.nb, c + 1, pe), w.q);
-                if (rc) return rc;
-            }
-        }
-        if (pe < w.nb) {
-            g.A = M; g.B = M; g.C = M;
-            int rc;
-            if ((ob & 1) == 0) {        // panel boundaries are 128-aligned: 128x128 tiles, K = 64 * ob
-                GemmArgs h = g;
-                h.nb = w.nb / 2; h.p0 = J / 2; h.p1 = pe / 2; h.p2 = pe / 2; h.p3 = w.nb / 2;
-                rc = launch_gemm<T, OP_SYRK, 128>(st, h, trapezoid_tiles(w.nb / 2, pe / 2, w.nb / 2), w.q);
-            } else {
-                g.p0 = J; g.p1 = pe; g.p2 = pe; g.p3 = w.nb;
-                rc = launch_gemm<T, OP_SYRK>(st, g, trapezoid_tiles(w.nb, pe, w.nb), w.q);
-            }
+    for (int c = J; c < pe; ++c) {
+        hipLaunchKernelGGL((leaf_kernel<T>), dim3(w.q), dim3(256), 0, st, M, W, w.mat, w.npad, c, logdet, info,
+                           g_debug_mask);
+        CHECK_LAUNCH("leaf_kernel");
+        if (c + 1 >= w.nb) break;
+        g.A = M; g.B = W; g.C = M; g.p0 = c; g.p1 = g.p2 = g.p3 = 0;
+        int rc = launch_gemm<T, OP_TRMM_PANEL>(st, g, w.nb - 1 - c, w.q);
+        if (rc) return rc;
+        if (c + 1 < pe) {
+            g.A = M; g.B = M; g.C = M; g.p0 = c; g.p1 = c + 1; g.p2 = c + 1; g.p3 = pe;
+            rc = launch_gemm<T, OP_SYRK>(st, g, trapezoid_tiles(w.nb, c + 1, pe), w.q);
             if (rc) return rc;
         }
     }
+    return 0;
+}
+
+// trailing update with the panel [J, pe) of the tile columns [c_lo, c_hi) (64-block units, all rows below)
+template <typename T>
+int potrf_trailing(hipStream_t st, const Ws& w, int J, int pe, int c_lo, int c_hi, bool tiles128) {
+    if (c_lo >= c_hi) return 0;
+    T* M = (T*)(w.base + w.off_M);
+    GemmArgs g;
+    g.sA = g.sB = g.sC = w.mat; g.ldA = g.ldB = g.ldC = w.npad;
+    g.A = M; g.B = M; g.C = M;
+    if (tiles128) {       // panel boundaries are 128-aligned: 128x128 tiles, K = 64 * (pe - J)
+        g.nb = w.nb / 2; g.p0 = J / 2; g.p1 = pe / 2; g.p2 = c_lo / 2; g.p3 = c_hi / 2;
+        return launch_gemm<T, OP_SYRK, 128>(st, g, trapezoid_tiles(w.nb / 2, c_lo / 2, c_hi / 2), w.q);
+    }
+    g.nb = w.nb; g.p0 = J; g.p1 = pe; g.p2 = c_lo; g.p3 = c_hi;
+    return launch_gemm<T, OP_SYRK>(st, g, trapezoid_tiles(w.nb, c_lo, c_hi), w.q);
+}
+
+// Two-level right-looking Cholesky with look-ahead.  Outer panels of `g_outer_blocks` 64-blocks; the trailing
+// matrix is touched once per outer panel with K = 64 * g_outer_blocks.  The panel factorisation is a chain of
+// short dependent launches that cannot fill the chip, the trailing update is wide: with look-ahead the panel
+// chain runs on a high-priority internal stream and only waits for the update of ITS OWN columns (the first
+// slice of the previous trailing update), so panel J+1 overlaps the rest of the trailing update of panel J.
+template <typename T>
+int do_potrf(hipStream_t st, const Ws& w) {
+    double* logdet = (double*)(w.base + w.off_logdet);
+    int* info = (int*)(w.base + w.off_info);
+    hipLaunchKernelGGL(zero_stats_kernel, dim3((w.q + 63) / 64), dim3(64), 0, st, logdet, info, w.q);
+    CHECK_LAUNCH("zero_stats");
+    const int ob = g_outer_blocks < 1 ? 1 : g_outer_blocks;
+    const bool t128 = (ob & 1) == 0;
+    if (!g_lookahead || w.nb <= ob) {
+        for (int J = 0; J < w.nb; J += ob) {
+            const int pe = J + ob < w.nb ? J + ob : w.nb;
+            int rc = potrf_panel<T>(st, w, J, pe);
+            if (rc) return rc;
+            rc = potrf_trailing<T>(st, w, J, pe, pe, w.nb, t128);
+            if (rc) return rc;
+        }
+        return 0;
+    }
+    StreamPool* pool = nullptr;
+    int rc = pool_get(pool);
+    if (rc) return rc;
+    hipStream_t sc = pool->chain;
+    HIPCHECK(hipEventRecord(pool->ev_fork2, st), "hipEventRecord");
+    HIPCHECK(hipStreamWaitEvent(sc, pool->ev_fork2, 0), "hipStreamWaitEvent");
+    if (g_lookahead == 2) {        // experiment: the plain single-stream schedule, but on the internal stream
+        for (int J = 0; J < w.nb; J += ob) {
+            const int pe = J + ob < w.nb ? J + ob : w.nb;
+            rc = potrf_panel<T>(sc, w, J, pe);
+            if (rc) return rc;
+            rc = potrf_trailing<T>(sc, w, J, pe, pe, w.nb, t128);
+            if (rc) return rc;
+        }
+        HIPCHECK(hipEventRecord(pool->ev_join2, sc), "hipEventRecord");
+        HIPCHECK(hipStreamWaitEvent(st, pool->ev_join2, 0), "hipStreamWaitEvent");
+        return 0;
+    }
+    if (g_lookahead == 3) {        // experiment: chain on the caller's stream, trailing updates on the internal one
+        hipStream_t su = sc;
+        for (int J = 0; J < w.nb; J += ob) {
+            const int pe = J + ob < w.nb ? J + ob : w.nb;
+            if (J > 0) HIPCHECK(hipStreamWaitEvent(st, pool->ev_next, 0), "hipStreamWaitEvent");
+            rc = potrf_panel<T>(st, w, J, pe);
+            if (rc) return rc;
+            HIPCHECK(hipEventRecord(pool->ev_panel, st), "hipEventRecord");
+            if (pe < w.nb) {
+                HIPCHECK(hipStreamWaitEvent(su, pool->ev_panel, 0), "hipStreamWaitEvent");
+                const int mid = pe + ob < w.nb ? pe + ob : w.nb;
+                rc = potrf_trailing<T>(su, w, J, pe, pe, mid, t128);
+                if (rc) return rc;
+                HIPCHECK(hipEventRecord(pool->ev_next, su), "hipEventRecord");
+                rc = potrf_trailing<T>(su, w, J, pe, mid, w.nb, t128);
+                if (rc) return rc;
+            }
+        }
+        HIPCHECK(hipEventRecord(pool->ev_join2, su), "hipEventRecord");
+        HIPCHECK(hipStreamWaitEvent(st, pool->ev_join2, 0), "hipStreamWaitEvent");
+        return 0;
+    }
+    for (int J = 0; J < w.nb; J += ob) {
+        const int pe = J + ob < w.nb ? J + ob : w.nb;
+        if (J > 0) HIPCHECK(hipStreamWaitEvent(sc, pool->ev_next, 0), "hipStreamWaitEvent");
+        rc = potrf_panel<T>(sc, w, J, pe);
+        if (rc) return rc;
+        HIPCHECK(hipEventRecord(pool->ev_panel, sc), "hipEventRecord");
+        if (pe < w.nb) {
+            HIPCHECK(hipStreamWaitEvent(st, pool->ev_panel, 0), "hipStreamWaitEvent");
+            const int mid = pe + ob < w.nb ? pe + ob : w.nb;          // columns of the NEXT panel first
+            rc = potrf_trailing<T>(st, w, J, pe, pe, mid, t128);
+            if (rc) return rc;
+            HIPCHECK(hipEventRecord(pool->ev_next, st), "hipEventRecord");
+            rc = potrf_trailing<T>(st, w, J, pe, mid, w.nb, t128);
+            if (rc) return rc;
+        }
+    }
+    HIPCHECK(hipEventRecord(pool->ev_join2, sc), "hipEventRecord");
+    HIPCHECK(hipStreamWaitEvent(st, pool->ev_join2, 0), "hipStreamWaitEvent");
     return 0;
 }
 
@@ -975,45 +1121,6 @@ int do_potri(hipStream_t st, const Ws& w) {
     int rc = do_trtri<T>(st, w);
     if (rc) return rc;
     return do_lauum<T>(st, w);
-}
-
-// ---------------------------------------------------------------------------------------------------
-// Component groups on internal streams.  The Cholesky and the triangular inverse are chains of short,
-// dependent launches (64 diagonal blocks in sequence, shrinking trailing updates, small inverse levels): one
-// chain cannot fill 256 CUs.  The components are independent, so they are split into up to `g_groups` groups,
-// each chain on its own stream; the hardware overlaps the diagonal block of one group with the trailing updates
-// of another and fills the tail of one launch with the head of the next.  The big uniform launches (build,
-// A^-1 = W^T W, symv, gradient contraction) stay single launches over all components on the caller's stream.
-// Streams/events are created once per device and kept (lcgp_shutdown() releases them).
-// ---------------------------------------------------------------------------------------------------
-constexpr int MAX_GROUPS = 8;
-int g_groups = 1;                       // lcgp_set_tuning key 1 (measured: > 2 groups run slower, see DESIGN.md)
-struct StreamPool {
-    bool ready = false;
-    hipStream_t s[MAX_GROUPS];
-    hipEvent_t fork, join[MAX_GROUPS];
-};
-StreamPool g_pool[16];
-
-int pool_get(StreamPool*& out) {
-    int dev = 0;
-    hipError_t e = hipGetDevice(&dev);
-    if (e != hipSuccess) return fail("hipGetDevice", e);
-    if (dev < 0 || dev >= 16) return bad("device index out of range");
-    StreamPool& p = g_pool[dev];
-    if (!p.ready) {
-        for (int i = 0; i < MAX_GROUPS; ++i) {
-            e = hipStreamCreateWithFlags(&p.s[i], hipStreamNonBlocking);
-            if (e != hipSuccess) return fail("hipStreamCreateWithFlags", e);
-            e = hipEventCreateWithFlags(&p.join[i], hipEventDisableTiming);
-            if (e != hipSuccess) return fail("hipEventCreateWithFlags", e);
-        }
-        e = hipEventCreateWithFlags(&p.fork, hipEventDisableTiming);
-        if (e != hipSuccess) return fail("hipEventCreateWithFlags", e);
-        p.ready = true;
-    }
-    out = &p;
-    return 0;
 }
 
 // view of the workspace restricted to components [k0, k0 + kq)
@@ -1174,6 +1281,14 @@ int lcgp_set_tuning(int key, int value) {
         g_debug_mask = value;
         return 0;
     }
+    if (key == 3) {
+        g_lookahead = value;
+        return 0;
+    }
+    if (key == 4) {
+        g_chain_prio = value ? 1 : 0;
+        return 0;
+    }
     if (key == 1) {
         if (value < 1 || value > MAX_GROUPS) return bad("component groups must be in [1, 8]");
         g_groups = value;
@@ -1191,6 +1306,11 @@ int lcgp_shutdown(void) {
             (void)hipEventDestroy(p.join[i]);
         }
         (void)hipEventDestroy(p.fork);
+        (void)hipStreamDestroy(p.chain);
+        (void)hipEventDestroy(p.ev_panel);
+        (void)hipEventDestroy(p.ev_next);
+        (void)hipEventDestroy(p.ev_fork2);
+        (void)hipEventDestroy(p.ev_join2);
         p.ready = false;
     }
     return 0;
