@@ -35,8 +35,10 @@ def parse():
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--config', type=int, default=3, help='synthetic config id of lcgp_amd/synth.py (3 = headline)')
     ap.add_argument('--n', type=int, default=None, help='override n (debug only; invalidates the headline metric)')
+    ap.add_argument('--q', type=int, default=None, help='override q (debug only: e.g. one rank\'s share of the components)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-stages', action='store_true')
+    ap.add_argument('--backend', default='nccl', help='process-group backend for --gpus > 1 (nccl = RCCL)')
     return ap.parse_args()
 
 
@@ -148,10 +150,15 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', '1'))
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs a GPU (the hot path has no CPU fallback)')
-    torch.cuda.set_device(local_rank)
+    ndev = torch.cuda.device_count()
+    dev_index = local_rank % ndev          # (more ranks than devices only happens in single-GPU rehearsals)
+    torch.cuda.set_device(dev_index)
     import torch.distributed as dist
     if world > 1:
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+        if args.backend == 'nccl':
+            dist.init_process_group('nccl', device_id=torch.device('cuda', dev_index))
+        else:
+            dist.init_process_group(args.backend)
     assert world == args.gpus, 'launch with torch.distributed.run --nproc-per-node %d' % args.gpus
 
     from lcgp_amd import LCGP, synth, _hip
@@ -166,9 +173,11 @@ def main():
     if os.environ.get('LCGP_GROUPS'):
         _hip.check(_hip.load().lcgp_set_tuning(1, int(os.environ['LCGP_GROUPS'])), 'lcgp_set_tuning')
     over = {} if args.n is None else dict(n=args.n)
+    if args.q is not None:
+        over['q'] = args.q
     x, y, cfg = synth.make_config(args.config, **over)
     dtype = 'float64' if cfg['dtype'] == 'f64' else 'float32'
-    m = LCGP(y=y, x=x, q=cfg['q'], submethod=cfg['submethod'], dtype=dtype, device='cuda:%d' % local_rank)
+    m = LCGP(y=y, x=x, q=cfg['q'], submethod=cfg['submethod'], dtype=dtype, device='cuda:%d' % dev_index)
     pts = synth.param_points(args.config, m._get_flat())
 
     def barrier():
@@ -188,7 +197,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device='cuda')
+        tt = torch.tensor([dt], dtype=torch.float64, device='cuda' if args.backend == 'nccl' else 'cpu')
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 
@@ -218,7 +227,8 @@ def main():
         traffic = None
         try:
             tj = json.load(open(os.path.join(ROOT, 'profiles', 'traffic.json')))
-            traffic = tj.get('tile_gemm_lauum_bytes_per_launch')
+            if world == 1 and args.config == 3 and args.n is None and args.q is None:   # measured for that launch only
+                traffic = tj.get('tile_gemm_lauum_bytes_per_launch')
         except Exception:
             pass
         out['roofline'] = dict(bound='mfma', kernel='tile_gemm<double, OP_LAUUM> (A^-1 = W^T W, one launch per evaluation)',
@@ -238,7 +248,7 @@ def main():
         # parity gate in the same run, same sample: component 0, HIP path vs the Cholesky-form oracle
         # (NLL 1e-6 relative, gradient 1e-5 relative to max |g|)
         from lcgp_amd.engine import HotPathEngine
-        eng = HotPathEngine(m.x.numpy()[:ns], m.y.numpy()[:, :ns], None, 1, dtype, 'cuda:%d' % local_rank)
+        eng = HotPathEngine(m.x.numpy()[:ns], m.y.numpy()[:, :ns], None, 1, dtype, 'cuda:%d' % dev_index)
         lLmb, lLmb0, ls2b, lnug = (t.numpy() for t in m.get_param())
         th = np.concatenate([lLmb[0], [lLmb0[0], lnug[0], m.diag_D.numpy()[0]], m.phi.numpy()[:, 0] / np.exp(0.5 * ls2b)])
         row = eng.evaluate(th[None, :])[0]

@@ -244,6 +244,9 @@ __device__ __forceinline__ double fast_rcp(double a) {
     return x;
 }
 
+// (measured alternatives, all slower on MI355X: fully unrolled step loop 38-41 us per block; pivot column broadcast
+// with v_readlane instead of LDS 36 us; owner lanes publishing 1/pivot at the end of the previous step 36 us; this
+// version 27 us.)
 // 16 pivot steps [s0, s0 + 16) of the in-register Cholesky; rows rg + 4m with m < M0 lie above the pivots of this
 // group and are skipped statically.  colbuf is permuted so that the 16 column entries a wave needs (rows rg + 4m)
 // are contiguous: row i sits at (i & 3) * 16 + (i >> 2).
@@ -280,8 +283,6 @@ __global__ __launch_bounds__(256) void leaf_kernel(T* __restrict__ M, T* __restr
     __shared__ double dinv[TS];
     __shared__ double a[TS][TS + 1];
     __shared__ double w[TS][TS + 1];
-    __shared__ double t[3][16][17];   // T_ab of the current block distance only (keeps the LDS footprint < 80 KB so
-                                      // that this kernel can share a CU with a 128x128 tile workgroup)
     const int k = blockIdx.x;
     const int tid = threadIdx.x;
     T* Mb = M + (size_t)k * mat + (size_t)jb * TS * npad + (size_t)jb * TS;
@@ -340,25 +341,32 @@ __global__ __launch_bounds__(256) void leaf_kernel(T* __restrict__ M, T* __restr
         for (int i = 0; i < 16; ++i) w[b0 + i][b0 + cl] = wc[i];
     }
     __syncthreads();
-    // (b) off-diagonal blocks by distance:  T_ab = sum_{m=b}^{a-1} L_am W_mb ;  W_ab = -W_aa T_ab
-    const int ei = tid >> 4, ej = tid & 15;
-    for (int dist = 1; dist < 4; ++dist) {
-        for (int bb = 0; bb + dist < 4; ++bb) {
-            const int ab = bb + dist;
-            double sacc = 0.0;
-            for (int mb = bb; mb < ab; ++mb)
+    // (b) off-diagonal 16x16 blocks by distance:  T_ab = sum_{m=b}^{a-1} L_am W_mb ;  W_ab = -W_aa T_ab,
+    // one wave per block pair on the fp64 MFMA.  The accumulator of T (lane: col = l & 15, rows (l >> 4) + 4 reg)
+    // is exactly the B-operand fragment of the second product (k = 4 step + (l >> 4)), so it is fed straight back.
+    {
+        const int wave = tid >> 6, lane = tid & 63;
+        const int li = lane & 15, lq = lane >> 4;
+        for (int dist = 1; dist < 4; ++dist) {
+            if (wave + dist < 4) {
+                const int bb = wave, ab = wave + dist;
+                d4 tacc = {0.0, 0.0, 0.0, 0.0};
+                for (int mb = bb; mb < ab; ++mb) {
 #pragma unroll
-                for (int m = 0; m < 16; ++m) sacc = fma(a[ab * 16 + ei][mb * 16 + m], w[mb * 16 + m][bb * 16 + ej], sacc);
-            t[bb][ei][ej] = sacc;
+                    for (int st = 0; st < 4; ++st)
+                        tacc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[ab * 16 + li][mb * 16 + 4 * st + lq],
+                                                                    w[mb * 16 + 4 * st + lq][bb * 16 + li], tacc, 0, 0, 0);
+                }
+                d4 wacc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int st = 0; st < 4; ++st)
+                    wacc = __builtin_amdgcn_mfma_f64_16x16x4f64(w[ab * 16 + li][ab * 16 + 4 * st + lq], tacc[st], wacc,
+                                                                0, 0, 0);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) w[ab * 16 + lq + 4 * e][bb * 16 + li] = -wacc[e];
+            }
+            __syncthreads();
         }
-        __syncthreads();
-        for (int bb = 0; bb + dist < 4; ++bb) {
-            const int ab = bb + dist;
-            double sacc = 0.0;
-            for (int m = 0; m <= ei; ++m) sacc = fma(w[ab * 16 + ei][ab * 16 + m], t[bb][m][ej], sacc);
-            w[ab * 16 + ei][bb * 16 + ej] = -sacc;
-        }
-        __syncthreads();
     }
 #pragma unroll
     for (int m = 0; m < 16; ++m) {
