@@ -53,6 +53,8 @@ int lcgp_out_width(int d, int p);
 
 /* performance knobs (process-wide, for experiments; results do not depend on them beyond rounding):
  *   key 0: width of the outer Cholesky panel in 64-column blocks (default 4);
+ *   key 5: width of the Cholesky super-panel in 64-column blocks (default 0 = the panel width, i.e. off): trailing updates of the panels stop at
+ *          the super-panel boundary, the rest of the matrix is updated once per super-panel;
  *   key 3: 1 = look-ahead Cholesky (panel chain on an internal stream), 0 (default) = single stream;
  *   key 4: 1 = create that internal stream with the highest priority;
  *   key 1: number of component groups whose factorisation chains run on internal streams (default 1 = off, max 8). */

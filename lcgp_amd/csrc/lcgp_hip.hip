@@ -938,6 +938,8 @@ int pool_get(StreamPool*& out) {
 }
 
 int g_outer_blocks = 4;   // width of the outer Cholesky panel in 64-blocks (lcgp_set_tuning key 0)
+int g_super_blocks = 0;   // width of the Cholesky super-panel in 64-blocks (lcgp_set_tuning key 5); 0 = same as the panel
+                          // (measured: 8, 16, 32 are not faster at n=4096)
 int g_debug_mask = 0;     // timing experiments only (lcgp_set_tuning key 2): 1 = skip pivots, 2 = skip inverse
 
 inline int trapezoid_tiles(int nb, int c_lo, int c_hi) {
@@ -1015,11 +1017,21 @@ int do_potrf(hipStream_t st, const Ws& w) {
     const int ob = g_outer_blocks < 1 ? 1 : g_outer_blocks;
     const bool t128 = (ob & 1) == 0;
     if (!g_lookahead || w.nb <= ob) {
-        for (int J = 0; J < w.nb; J += ob) {
-            const int pe = J + ob < w.nb ? J + ob : w.nb;
-            int rc = potrf_panel<T>(st, w, J, pe);
-            if (rc) return rc;
-            rc = potrf_trailing<T>(st, w, J, pe, pe, w.nb, t128);
+        // three levels: 64-column steps inside a panel of `ob` blocks, panels inside a super-panel of `sb` blocks
+        // (their trailing updates stop at the super-panel boundary, K = 64 ob), and one far update per super-panel
+        // with K = 64 sb: most flops of the trailing update then run as few long-K launches
+        int sb = g_super_blocks < ob ? ob : g_super_blocks;
+        sb = sb / ob * ob;
+        for (int S = 0; S < w.nb; S += sb) {
+            const int se = S + sb < w.nb ? S + sb : w.nb;
+            for (int J = S; J < se; J += ob) {
+                const int pe = J + ob < se ? J + ob : se;
+                int rc = potrf_panel<T>(st, w, J, pe);
+                if (rc) return rc;
+                rc = potrf_trailing<T>(st, w, J, pe, pe, se, t128);
+                if (rc) return rc;
+            }
+            int rc = potrf_trailing<T>(st, w, S, se, se, w.nb, t128);
             if (rc) return rc;
         }
         return 0;
@@ -1295,6 +1307,11 @@ int lcgp_set_tuning(int key, int value) {
     }
     if (key == 4) {
         g_chain_prio = value ? 1 : 0;
+        return 0;
+    }
+    if (key == 5) {
+        if (value < 0 || value > 1024) return bad("super-panel width must be in [0, 1024] blocks");
+        g_super_blocks = value;
         return 0;
     }
     if (key == 1) {

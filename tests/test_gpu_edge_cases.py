@@ -1,0 +1,149 @@
+"""Edge cases of the HIP path against the oracle: tiny and ragged sizes, maximum input dimension, duplicated
+inputs (kernel collisions), parameters at the SoftClip bounds, predict with one and with many new inputs,
+float32 on the replicated path."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from lcgp_amd import LCGP, synth, _hip
+from oracle import lcgp_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+def _same(m, o, u, nll_tol=1e-6, grad_tol=1e-5):
+    o.phi = m.phi.numpy().copy()
+    v1, g1 = m.loss_and_grad(u)
+    v2, g2 = o.loss_and_grad_unconstrained(u)
+    assert np.isfinite(v1) and np.all(np.isfinite(g1))
+    assert abs(v1 - v2) <= nll_tol * max(abs(v2), 1e-12), (v1, v2)
+    assert np.max(np.abs(g1 - g2)) <= grad_tol * max(np.max(np.abs(g2)), 1e-12)
+
+
+@pytest.mark.parametrize('n,d,p,q', [(3, 1, 1, 1), (2, 2, 2, 1), (127, 1, 2, 2), (128, 2, 3, 3), (129, 3, 2, 2)])
+def test_tiny_and_tile_boundary_sizes(n, d, p, q):
+    x, y = synth.make_full(300 + n, n, d, p, q)
+    kw = dict(q=q, robust_mean=False)     # robust spread of a 2-3 point row can be 0 -> the reference gives NaN too
+    m = LCGP(y=y, x=x, **kw)
+    o = orc.OracleLCGP(y=y, x=x, **kw)
+    _same(m, o, o.get_unconstrained())
+    out = m.predict(x[:1])
+    assert out[0].shape == (p, 1) and np.all(np.isfinite(out[0].numpy()))
+
+
+def test_maximum_input_dimension_and_refusal_above_it():
+    x, y = synth.make_full(316, 90, 16, 3, 2)
+    m = LCGP(y=y, x=x, q=2)
+    o = orc.OracleLCGP(y=y, x=x, q=2)
+    _same(m, o, synth.param_points(316, o.get_unconstrained())[1])
+    x17, y17 = synth.make_full(317, 40, 17, 2, 2)
+    m17 = LCGP(y=y17, x=x17, q=2)
+    with pytest.raises(RuntimeError, match='d must be'):
+        m17.loss()
+
+
+def test_duplicated_inputs_in_full_mode():
+    """identical rows of x give identical rows of C (the nugget only sits on the diagonal)."""
+    x, y = synth.make_full(320, 100, 2, 3, 3)
+    x[10] = x[3]
+    x[50:60] = x[20:30]
+    m = LCGP(y=y, x=x, q=3)
+    o = orc.OracleLCGP(y=y, x=x, q=3)
+    for u in synth.param_points(320, o.get_unconstrained()):
+        _same(m, o, u)
+
+
+def test_parameters_near_the_softclip_bounds():
+    x, y = synth.make_full(321, 150, 2, 3, 2)
+    m = LCGP(y=y, x=x, q=2)
+    o = orc.OracleLCGP(y=y, x=x, q=2)
+    u0 = o.get_unconstrained()
+    for shift in (-25.0, +12.0):          # lengthscales ~1e-6 (C -> nugget-free identity) / large (C -> all ones)
+        u = u0.copy()
+        u[:4] = u0[:4] + shift
+        _same(m, o, u, grad_tol=1e-4)
+    u = u0.copy()
+    u[6:8] = 30.0                         # nugget at its upper bound e^-2
+    _same(m, o, u)
+    u = u0.copy()
+    u[6:8] = -40.0                        # nugget at its lower bound e^-16
+    _same(m, o, u)
+
+
+@pytest.mark.parametrize('n0', [1, 63, 64, 65, 700])
+def test_predict_sizes(n0):
+    x, y = synth.make_full(322, 200, 2, 3, 3)
+    m = LCGP(y=y, x=x, q=3)
+    o = orc.OracleLCGP(y=y, x=x, q=3)
+    o.phi = m.phi.numpy().copy()
+    u = synth.param_points(322, o.get_unconstrained())[1]
+    m._set_flat(u)
+    o.set_unconstrained(u)
+    x0 = np.random.default_rng(n0).uniform(-0.2, 1.2, (n0, 2))     # also outside the training box
+    got = m.predict(x0)
+    want = o.predict(x0)
+    for a, b in zip(got, want):
+        assert a.shape == (3, n0)
+        np.testing.assert_allclose(a.numpy(), b, rtol=1e-6, atol=1e-9)
+
+
+def test_var_threshold_and_single_component():
+    x, y = synth.make_full(323, 120, 2, 6, 2)
+    m = LCGP(y=y, x=x, var_threshold=0.6)
+    o = orc.OracleLCGP(y=y, x=x, var_threshold=0.6)
+    assert m.q == o.q
+    _same(m, o, o.get_unconstrained())
+    m1 = LCGP(y=y, x=x, q=1)
+    o1 = orc.OracleLCGP(y=y, x=x, q=1)
+    _same(m1, o1, o1.get_unconstrained())
+
+
+def test_many_outputs():
+    x, y = synth.make_full(324, 96, 2, 150, 3)
+    m = LCGP(y=y, x=x, q=3)
+    o = orc.OracleLCGP(y=y, x=x, q=3)
+    _same(m, o, synth.param_points(324, o.get_unconstrained())[1])
+
+
+def test_float32_replicated_path():
+    x, y = synth.make_rep(325, 300, 3, 2, 4, 4)
+    m64 = LCGP(y=y, x=x, submethod='rep')
+    m32 = LCGP(y=y, x=x, submethod='rep', dtype='float32')
+    u = m64._get_flat()
+    v64, g64 = m64.loss_and_grad(u)
+    v32, g32 = m32.loss_and_grad(u)
+    assert abs(v32 - v64) <= 1e-3 * abs(v64)
+    assert np.max(np.abs(g32 - g64)) <= 2e-2 * np.max(np.abs(g64))
+    p64 = m64.predict(x[:20])[0].numpy()
+    p32 = m32.predict(x[:20])[0].numpy()
+    np.testing.assert_allclose(p32, p64, rtol=5e-3, atol=5e-3)
+
+
+def test_c_abi_argument_checks():
+    lib = _hip.load()
+    nbytes = C.c_size_t(0)
+    assert lib.lcgp_workspace_bytes(2, 10, 2, 2, 1, C.byref(nbytes)) < 0          # bad dtype
+    assert lib.lcgp_workspace_bytes(0, 0, 2, 2, 1, C.byref(nbytes)) < 0           # n < 1
+    assert lib.lcgp_workspace_bytes(0, 10, 2, 2, 0, C.byref(nbytes)) < 0          # q_local < 1
+    assert lib.lcgp_nll_grad(None, 0, 10, 2, 2, 1, None, None, None, None, None, None) < 0
+    assert b'NULL' in lib.lcgp_last_error()
+    assert lib.lcgp_set_tuning(99, 1) < 0
+    assert lib.lcgp_set_tuning(0, 4) == 0
+
+
+def test_tuning_knobs_do_not_change_results():
+    x, y = synth.make_full(326, 700, 3, 4, 4)
+    m = LCGP(y=y, x=x, q=4)
+    u = synth.param_points(326, m._get_flat())[1]
+    ref_v, ref_g = m.loss_and_grad(u)
+    lib = _hip.load()
+    try:
+        for key, val in ((0, 2), (0, 8), (5, 8), (1, 2), (3, 1)):
+            assert lib.lcgp_set_tuning(key, val) == 0
+            v, g = m.loss_and_grad(u)
+            assert abs(v - ref_v) <= 1e-11 * abs(ref_v)
+            assert np.max(np.abs(g - ref_g)) <= 1e-10 * np.max(np.abs(ref_g))
+            lib.lcgp_set_tuning(0, 4); lib.lcgp_set_tuning(5, 0); lib.lcgp_set_tuning(1, 1); lib.lcgp_set_tuning(3, 0)
+    finally:
+        lib.lcgp_set_tuning(0, 4); lib.lcgp_set_tuning(5, 0); lib.lcgp_set_tuning(1, 1); lib.lcgp_set_tuning(3, 0)
