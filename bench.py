@@ -164,6 +164,10 @@ def main():
     from lcgp_amd import LCGP, synth, _hip
     if os.environ.get('LCGP_OB'):
         _hip.check(_hip.load().lcgp_set_tuning(0, int(os.environ['LCGP_OB'])), 'lcgp_set_tuning')
+    if os.environ.get('LCGP_SMALL'):
+        _hip.check(_hip.load().lcgp_set_tuning(6, int(os.environ['LCGP_SMALL'])), 'lcgp_set_tuning')
+    if os.environ.get('LCGP_SMALL_LAUUM'):
+        _hip.check(_hip.load().lcgp_set_tuning(7, int(os.environ['LCGP_SMALL_LAUUM'])), 'lcgp_set_tuning')
     if os.environ.get('LCGP_SB'):
         _hip.check(_hip.load().lcgp_set_tuning(5, int(os.environ['LCGP_SB'])), 'lcgp_set_tuning')
     if os.environ.get('LCGP_PRIO'):

@@ -732,7 +732,7 @@ __global__ __launch_bounds__(256) void grad_kernel(const T* __restrict__ V, size
                 double s = fabs(xr[i][jj] - xc[j][jj]);
                 poly *= 1.0 + s;
                 ssum -= s;
-                tt[jj] = s * s / (1.0 + s);
+                tt[jj] = s * s * fast_rcp(1.0 + s);   // (rcp + 2 Newton steps: full double accuracy, 4x fewer instructions than IEEE division)
             } else {
                 tt[jj] = 0.0;
             }
@@ -1097,42 +1097,66 @@ int do_potrf(hipStream_t st, const Ws& w) {
     return 0;
 }
 
-template <typename T>
-int do_trtri(hipStream_t st, const Ws& w) {
+// With few components in flight the 128x128 launches of the inverse are bounded by their LONGEST tile (one tile with
+// K = 4096 keeps a CU busy for ~0.5 ms while the rest of the chip idles): below `g_small_tiles` 128-tiles per
+// launch the same products run on 64x64 tiles (4x more, 4x shorter tiles).  lcgp_set_tuning key 6.
+int g_small_tiles_trtri = 4200;   // measured at n=4096: 64-tiles win for q_local <= 4, lose at 8
+int g_small_tiles_lauum = 1024;   //                      64-tiles win for q_local = 1 only
+
+inline bool use_small_tiles(const Ws& w, int threshold) {
+    const int nb2 = w.nb / 2;
+    return (long long)w.q * (nb2 * (nb2 + 1) / 2) < threshold;
+}
+
+template <typename T, int TM>
+int trtri_levels(hipStream_t st, const Ws& w, int first_mb) {
     T* M = (T*)(w.base + w.off_M);
     T* W = (T*)(w.base + w.off_W);
     T* V = (T*)(w.base + w.off_V);
     GemmArgs g;
-    g.sA = g.sB = g.sC = w.mat; g.ldA = g.ldB = g.ldC = w.npad; g.p1 = g.p2 = g.p3 = 0;
-    // level 0 joins pairs of 64-blocks (64x64 tiles); every further level works on 128x128 tiles
-    g.nb = w.nb; g.p0 = 1; g.p1 = w.nb / 2;
-    g.A = M; g.B = W; g.C = V;
-    int rc = launch_gemm<T, OP_TRTRI_T, 64>(st, g, w.nb / 2, w.q);
-    if (rc) return rc;
-    g.A = W; g.B = V; g.C = W;
-    rc = launch_gemm<T, OP_TRTRI_W, 64>(st, g, w.nb / 2, w.q);
-    if (rc) return rc;
-    const int nb2 = w.nb / 2;
-    g.nb = nb2;
-    for (int mb = 1; mb < nb2; mb *= 2) {
-        const int pairs = (nb2 + 2 * mb - 1) / (2 * mb);
+    g.sA = g.sB = g.sC = w.mat; g.ldA = g.ldB = g.ldC = w.npad; g.p2 = g.p3 = 0;
+    const int nbt = w.npad / TM;
+    g.nb = nbt;
+    for (int mb = first_mb; mb < nbt; mb *= 2) {
+        const int pairs = (nbt + 2 * mb - 1) / (2 * mb);
         g.p0 = mb; g.p1 = pairs;
         g.A = M; g.B = W; g.C = V;
-        rc = launch_gemm<T, OP_TRTRI_T, 128>(st, g, pairs * mb * mb, w.q);
+        int rc = launch_gemm<T, OP_TRTRI_T, TM>(st, g, pairs * mb * mb, w.q);
         if (rc) return rc;
         g.A = W; g.B = V; g.C = W;
-        rc = launch_gemm<T, OP_TRTRI_W, 128>(st, g, pairs * mb * mb, w.q);
+        rc = launch_gemm<T, OP_TRTRI_W, TM>(st, g, pairs * mb * mb, w.q);
         if (rc) return rc;
     }
     return 0;
 }
 
 template <typename T>
+int do_trtri(hipStream_t st, const Ws& w) {
+    if (use_small_tiles(w, g_small_tiles_trtri)) return trtri_levels<T, 64>(st, w, 1);
+    // level 0 joins pairs of 64-blocks (64x64 tiles); every further level works on 128x128 tiles
+    GemmArgs g;
+    g.sA = g.sB = g.sC = w.mat; g.ldA = g.ldB = g.ldC = w.npad; g.p2 = g.p3 = 0;
+    g.nb = w.nb; g.p0 = 1; g.p1 = w.nb / 2;
+    g.A = (T*)(w.base + w.off_M); g.B = (T*)(w.base + w.off_W); g.C = (T*)(w.base + w.off_V);
+    int rc = launch_gemm<T, OP_TRTRI_T, 64>(st, g, w.nb / 2, w.q);
+    if (rc) return rc;
+    g.A = (T*)(w.base + w.off_W); g.B = (T*)(w.base + w.off_V); g.C = (T*)(w.base + w.off_W);
+    rc = launch_gemm<T, OP_TRTRI_W, 64>(st, g, w.nb / 2, w.q);
+    if (rc) return rc;
+    return trtri_levels<T, 128>(st, w, 1);
+}
+
+template <typename T>
 int do_lauum(hipStream_t st, const Ws& w) {
     GemmArgs g;
-    const int nb2 = w.nb / 2;
-    g.sA = g.sB = g.sC = w.mat; g.ldA = g.ldB = g.ldC = w.npad; g.nb = nb2; g.p0 = g.p1 = g.p2 = g.p3 = 0;
+    g.sA = g.sB = g.sC = w.mat; g.ldA = g.ldB = g.ldC = w.npad; g.p0 = g.p1 = g.p2 = g.p3 = 0;
     g.A = (T*)(w.base + w.off_W); g.B = g.A; g.C = (T*)(w.base + w.off_V);
+    if (use_small_tiles(w, g_small_tiles_lauum)) {
+        g.nb = w.nb;
+        return launch_gemm<T, OP_LAUUM, 64>(st, g, w.nb * (w.nb + 1) / 2, w.q);
+    }
+    const int nb2 = w.nb / 2;
+    g.nb = nb2;
     return launch_gemm<T, OP_LAUUM, 128>(st, g, nb2 * (nb2 + 1) / 2, w.q);
 }
 
@@ -1307,6 +1331,14 @@ int lcgp_set_tuning(int key, int value) {
     }
     if (key == 4) {
         g_chain_prio = value ? 1 : 0;
+        return 0;
+    }
+    if (key == 6) {
+        g_small_tiles_trtri = value;
+        return 0;
+    }
+    if (key == 7) {
+        g_small_tiles_lauum = value;
         return 0;
     }
     if (key == 5) {
