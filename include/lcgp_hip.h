@@ -58,6 +58,7 @@ int lcgp_out_width(int d, int p);
  *   key 6 / key 7: below this many 128x128 tiles per launch (components x tiles) the triangular inverse (6, default
  *          4200) / A^-1 = W^T W (7, default 1024) run on 64x64 tiles: with few components a launch is bounded by
  *          its longest tile (0 = always 128x128);
+ *   key 8: the same switch for the trailing update of the Cholesky (default 768);
  *   key 3: 1 = look-ahead Cholesky (panel chain on an internal stream), 0 (default) = single stream;
  *   key 4: 1 = create that internal stream with the highest priority;
  *   key 1: number of component groups whose factorisation chains run on internal streams (default 1 = off, max 8). */

@@ -245,33 +245,59 @@ __device__ __forceinline__ double fast_rcp(double a) {
 }
 
 // (measured alternatives, all slower on MI355X: fully unrolled step loop 38-41 us per block; pivot column broadcast
-// with v_readlane instead of LDS 36 us; owner lanes publishing 1/pivot at the end of the previous step 36 us; this
-// version 27 us.)
-// 16 pivot steps [s0, s0 + 16) of the in-register Cholesky; rows rg + 4m with m < M0 lie above the pivots of this
-// group and are skipped statically.  colbuf is permuted so that the 16 column entries a wave needs (rows rg + 4m)
-// are contiguous: row i sits at (i & 3) * 16 + (i >> 2).
+// with v_readlane instead of LDS 36 us; owner lanes publishing 1/pivot at the end of the previous step 36 us; one
+// pivot per barrier 27 us.)
+// 16 pivot steps [s0, s0 + 16) of the in-register Cholesky, TWO pivots per barrier.  Rows rg + 4m with m < M0 lie
+// above the pivots of this group and are skipped statically; the step loop is rolled on purpose (a fully unrolled
+// chain runs at instruction-fetch speed).  Per pair (s, s+1) the owner lanes publish both columns as they stand
+// (column s+1 NOT yet updated by pivot s), permuted so that the 16 entries a wave needs (rows rg + 4m) are
+// contiguous: row i sits at (i & 3) * 16 + (i >> 2).  Every thread then factors the 2x2 pivot block itself
+// (l = a/c_ss, b' = b - a l) and applies the rank-2 update  a_ij -= c_i (c_j/c_ss) + c'_i (c'_j/b')  with
+// c' = c_{.,s+1} - c_{.,s} l:  one barrier and one LDS round trip per two pivots.
 template <int M0>
-__device__ __forceinline__ void leaf_pivot_group(double (&r)[16], double (*colbuf)[TS], int s0, int cj, int rg,
+__device__ __forceinline__ void leaf_pivot_group(double (&r)[16], double (*colbuf)[2][TS], int s0, int cj, int rg,
                                                  double& piv, int& first_bad, int jb) {
 #pragma unroll 1
-    for (int s = s0; s < s0 + 16; ++s) {
-        double* cb = colbuf[s & 1];
+    for (int s = s0; s < s0 + 16; s += 2) {
+        double* cb0 = colbuf[(s >> 1) & 1][0];
+        double* cb1 = colbuf[(s >> 1) & 1][1];
         if (cj == s) {
 #pragma unroll
-            for (int m = M0; m < 16; ++m) cb[rg * 16 + m] = r[m];
+            for (int m = M0; m < 16; ++m) cb0[rg * 16 + m] = r[m];
+        }
+        if (cj == s + 1) {
+#pragma unroll
+            for (int m = M0; m < 16; ++m) cb1[rg * 16 + m] = r[m];
         }
         __syncthreads();
-        const double css = cb[((s & 3) << 4) + (s >> 2)];
-        const double ccj = cb[((cj & 3) << 4) + (cj >> 2)];
-        double c[16];
+        const int ps = ((s & 3) << 4) + (s >> 2), ps1 = (((s + 1) & 3) << 4) + ((s + 1) >> 2);
+        const int pc = ((cj & 3) << 4) + (cj >> 2);
+        const double css = cb0[ps], a10 = cb0[ps1], b11 = cb1[ps1];
+        const double ccj0 = cb0[pc], ccj1 = cb1[pc];
+        double c0[16], c1[16];
 #pragma unroll
-        for (int m = M0; m < 16; ++m) c[m] = cb[rg * 16 + m];     // wave-uniform address: LDS broadcast
-        if (!(css > 0.0) && first_bad == 0) first_bad = jb * TS + s + 1;
+        for (int m = M0; m < 16; ++m) {       // wave-uniform addresses: LDS broadcasts
+            c0[m] = cb0[rg * 16 + m];
+            c1[m] = cb1[rg * 16 + m];
+        }
+        const double r1 = fast_rcp(css);
+        const double l10 = a10 * r1;
+        const double bp = fma(-a10, l10, b11);
+        const double r2 = fast_rcp(bp);
+        if (first_bad == 0) {
+            if (!(css > 0.0)) first_bad = jb * TS + s + 1;
+            else if (!(bp > 0.0)) first_bad = jb * TS + s + 2;
+        }
         if (cj == s) piv = css;
+        if (cj == s + 1) piv = bp;
         if (cj > s) {
-            const double tt = ccj * fast_rcp(css);
+            const double t1 = ccj0 * r1;
+            const double t2 = cj > s + 1 ? fma(-ccj0, l10, ccj1) * r2 : 0.0;
 #pragma unroll
-            for (int m = M0; m < 16; ++m) r[m] = fma(-c[m], tt, r[m]);
+            for (int m = M0; m < 16; ++m) {
+                const double c1p = fma(-c0[m], l10, c1[m]);
+                r[m] = fma(-c1p, t2, fma(-c0[m], t1, r[m]));
+            }
         }
     }
 }
@@ -279,7 +305,7 @@ __device__ __forceinline__ void leaf_pivot_group(double (&r)[16], double (*colbu
 template <typename T>
 __global__ __launch_bounds__(256) void leaf_kernel(T* __restrict__ M, T* __restrict__ W, size_t mat, int npad, int jb,
                                                    double* __restrict__ logdet, int* __restrict__ info, int dbg) {
-    __shared__ double colbuf[2][TS];
+    __shared__ double colbuf[2][2][TS];
     __shared__ double dinv[TS];
     __shared__ double a[TS][TS + 1];
     __shared__ double w[TS][TS + 1];
@@ -950,6 +976,7 @@ inline int trapezoid_tiles(int nb, int c_lo, int c_hi) {
 // step is  diagonal block -> panel TRMM -> rank-64 update of the REST OF THE PANEL only;  the trailing matrix
 // is touched once per outer panel with K = 64 * g_outer_blocks (read-modify-write traffic / g_outer_blocks).
 int g_chain_prio = 0;     // lcgp_set_tuning key 4: 1 = create the chain stream with the highest priority (before first use)
+int g_small_tiles_syrk = 768;   // lcgp_set_tuning key 8
 int g_lookahead = 0;      // lcgp_set_tuning key 3: 1 = panel chain on its own stream ahead of the trailing update.
                           // OFF by default: measured on MI355X / ROCm 7.2, as soon as one HIP stream waits on another
                           // (barrier packet) every kernel boundary on the running stream costs 20-40 us, so the
@@ -995,7 +1022,9 @@ int potrf_trailing(hipStream_t st, const Ws& w, int J, int pe, int c_lo, int c_h
     GemmArgs g;
     g.sA = g.sB = g.sC = w.mat; g.ldA = g.ldB = g.ldC = w.npad;
     g.A = M; g.B = M; g.C = M;
-    if (tiles128) {       // panel boundaries are 128-aligned: 128x128 tiles, K = 64 * (pe - J)
+    // 128x128 tiles when the panel boundaries are 128-aligned AND the launch has enough of them to fill the chip;
+    // a launch with few tiles is bounded by the duration of one tile, which is 4x shorter on 64x64 tiles
+    if (tiles128 && (long long)w.q * trapezoid_tiles(w.nb / 2, c_lo / 2, c_hi / 2) >= g_small_tiles_syrk) {
         g.nb = w.nb / 2; g.p0 = J / 2; g.p1 = pe / 2; g.p2 = c_lo / 2; g.p3 = c_hi / 2;
         return launch_gemm<T, OP_SYRK, 128>(st, g, trapezoid_tiles(w.nb / 2, c_lo / 2, c_hi / 2), w.q);
     }
@@ -1339,6 +1368,10 @@ int lcgp_set_tuning(int key, int value) {
     }
     if (key == 7) {
         g_small_tiles_lauum = value;
+        return 0;
+    }
+    if (key == 8) {
+        g_small_tiles_syrk = value;
         return 0;
     }
     if (key == 5) {
