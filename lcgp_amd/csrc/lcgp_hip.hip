@@ -72,7 +72,8 @@ inline Ws carve(int dtype, int n, int d, int p, int q, void* base) {
     w.off_V = o; o = align256(o + w.mat * q * w.esz);
     w.off_b = o; o = align256(o + (size_t)w.npad * q * w.esz);
     w.off_z = o; o = align256(o + (size_t)w.npad * q * w.esz);
-    w.off_part = o; o = align256(o + (size_t)w.ntile_lower * q * (DMAX + 2) * sizeof(double));
+    w.off_part = o; o = align256(o + (size_t)w.ntile_lower * q * 2 * TS * sizeof(double));   // symv partials (2 x 64 per
+                                                                                          // tile), then gradient partials
     w.off_logdet = o; o = align256(o + (size_t)q * sizeof(double));
     w.off_info = o; o = align256(o + (size_t)q * sizeof(int));
     w.total = o;
@@ -657,49 +658,60 @@ __global__ void bvec_kernel(T* __restrict__ b, int n, int npad, int d, int p, co
 }
 
 // ---------------------------------------------------------------------------------------------------
-// z = A^-1 b with A^-1 stored as lower 64x64 tiles.  One workgroup per (row block r, component):
-//   z_r = sum_{c <= r} V[r, c] b_c  +  sum_{r' > r} V[r', r]^T b_r'            (fixed summation order)
+// z = A^-1 b with A^-1 stored as lower 64x64 tiles, every tile read ONCE:
+//   symv_tile_kernel : tile (r, c) -> p1 = V_tile b_c (64 values, belongs to z_r) and, off the diagonal,
+//                      p2 = V_tile^T b_r (belongs to z_c); written to the partial buffer [tile][2][64]
+//   symv_reduce_kernel: z_R = sum_{c <= R} p1(R, c) + sum_{r > R} p2(r, R)      (fixed summation order)
 // ---------------------------------------------------------------------------------------------------
 template <typename T>
-__global__ __launch_bounds__(256) void symv_kernel(const T* __restrict__ V, size_t mat, int npad, int nb,
-                                                   const T* __restrict__ b, T* __restrict__ z) {
+__global__ __launch_bounds__(256) void symv_tile_kernel(const T* __restrict__ V, size_t mat, int npad,
+                                                        const T* __restrict__ b, double* __restrict__ part, int ntile) {
+    __shared__ double vt[TS][TS + 1];
     __shared__ double red[4][TS];
-    __shared__ double part1[TS];
-    const int k = blockIdx.y, r = blockIdx.x;
-    const T* Vk = V + (size_t)k * mat;
-    const T* bk = b + (size_t)k * npad;
-    const int tid = threadIdx.x;
-    // part 1: row i = tid >> 2, 16 columns per tile per thread
-    {
-        const int i = tid >> 2, q4 = tid & 3;
-        const T* row = Vk + (size_t)(r * TS + i) * npad;
-        double s = 0.0;
-        for (int c = 0; c <= r; ++c) {
-            const T* v = row + c * TS + q4 * 16;
-            const T* bb = bk + c * TS + q4 * 16;
-#pragma unroll
-            for (int e = 0; e < 16; ++e) s += (double)v[e] * (double)bb[e];
-        }
-        s += __shfl_xor(s, 1);
-        s += __shfl_xor(s, 2);
-        if (q4 == 0) part1[i] = s;
-    }
-    // part 2: column j = tid & 63 of the tiles below, rows g, g+4, ...
-    {
-        const int j = tid & 63, gq = tid >> 6;
-        double s = 0.0;
-        for (int rp = r + 1; rp < nb; ++rp) {
-            const T* base = Vk + (size_t)(rp * TS) * npad + r * TS + j;
-            const T* bb = bk + rp * TS;
-            for (int m = gq; m < TS; m += 4) s += (double)base[(size_t)m * npad] * (double)bb[m];
-        }
-        red[gq][j] = s;
-    }
-    __syncthreads();
+    __shared__ double br[TS], bc[TS];
+    const int k = blockIdx.y;
+    int r, c;
+    tri_decode(blockIdx.x, r, c);
+    const T* Vt = V + (size_t)k * mat + (size_t)r * TS * npad + (size_t)c * TS;
+    const int tid = threadIdx.x, j = tid & 63, g = tid >> 6;
     if (tid < TS) {
-        double s = part1[tid] + ((red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]));
-        z[(size_t)k * npad + r * TS + tid] = (T)s;
+        br[tid] = (double)b[(size_t)k * npad + r * TS + tid];
+        bc[tid] = (double)b[(size_t)k * npad + c * TS + tid];
     }
+    double v[16];
+#pragma unroll
+    for (int m = 0; m < 16; ++m) v[m] = (double)Vt[(size_t)(g * 16 + m) * npad + j];
+    __syncthreads();
+    double* dst = part + ((size_t)k * ntile + blockIdx.x) * 2 * TS;
+    // p2[j] = sum_i V[i][j] b_r[i]: each thread sums its 16 rows, then the 4 row groups
+    double s2 = 0.0;
+#pragma unroll
+    for (int m = 0; m < 16; ++m) {
+        s2 = fma(v[m], br[g * 16 + m], s2);
+        vt[g * 16 + m][j] = v[m];
+    }
+    red[g][j] = s2;
+    __syncthreads();
+    if (tid < TS) dst[TS + tid] = r == c ? 0.0 : (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
+    // p1[i] = sum_j V[i][j] b_c[j]: thread (i = tid & 63, g) sums columns 16 g .. 16 g + 15 from the LDS copy
+    double s1 = 0.0;
+#pragma unroll
+    for (int m = 0; m < 16; ++m) s1 = fma(vt[j][g * 16 + m], bc[g * 16 + m], s1);
+    __syncthreads();
+    red[g][j] = s1;
+    __syncthreads();
+    if (tid < TS) dst[tid] = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
+}
+
+template <typename T>
+__global__ __launch_bounds__(64) void symv_reduce_kernel(const double* __restrict__ part, int ntile, int npad, int nb,
+                                                         T* __restrict__ z) {
+    const int k = blockIdx.y, R = blockIdx.x, i = threadIdx.x;
+    const double* pk = part + (size_t)k * ntile * 2 * TS;
+    double s = 0.0;
+    for (int c = 0; c <= R; ++c) s += pk[((size_t)(R * (R + 1) / 2 + c)) * 2 * TS + i];
+    for (int r = R + 1; r < nb; ++r) s += pk[((size_t)(r * (r + 1) / 2 + R)) * 2 * TS + TS + i];
+    z[(size_t)k * npad + R * TS + i] = (T)s;
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -1205,7 +1217,7 @@ inline Ws sub_ws(const Ws& w, int k0, int kq) {
     v.off_V += (size_t)k0 * w.mat * w.esz;
     v.off_b += (size_t)k0 * w.npad * w.esz;
     v.off_z += (size_t)k0 * w.npad * w.esz;
-    v.off_part += (size_t)k0 * w.ntile_lower * (DMAX + 2) * sizeof(double);
+    v.off_part += (size_t)k0 * w.ntile_lower * 2 * TS * sizeof(double);
     v.off_logdet += (size_t)k0 * sizeof(double);
     v.off_info += (size_t)k0 * sizeof(int);
     return v;
@@ -1267,9 +1279,12 @@ int do_nll_grad(hipStream_t st, const Ws& w, const void* x, const void* Y, const
     if (rc) return rc;
     rc = do_lauum<T>(st, w);
     if (rc) return rc;
-    hipLaunchKernelGGL((symv_kernel<T>), dim3(w.nb, w.q), dim3(256), 0, st, (const T*)(w.base + w.off_V), w.mat, w.npad,
-                       w.nb, (const T*)b, z);
-    CHECK_LAUNCH("symv_kernel");
+    hipLaunchKernelGGL((symv_tile_kernel<T>), dim3(w.ntile_lower, w.q), dim3(256), 0, st, (const T*)(w.base + w.off_V),
+                       w.mat, w.npad, (const T*)b, (double*)(w.base + w.off_part), w.ntile_lower);
+    CHECK_LAUNCH("symv_tile_kernel");
+    hipLaunchKernelGGL((symv_reduce_kernel<T>), dim3(w.nb, w.q), dim3(64), 0, st, (const double*)(w.base + w.off_part),
+                       w.ntile_lower, w.npad, w.nb, z);
+    CHECK_LAUNCH("symv_reduce_kernel");
     if (w.d <= 2) launch_grad<T, 2>(st, w, x, sr, theta);
     else if (w.d <= 4) launch_grad<T, 4>(st, w, x, sr, theta);
     else if (w.d <= 6) launch_grad<T, 6>(st, w, x, sr, theta);

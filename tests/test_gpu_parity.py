@@ -241,3 +241,19 @@ def test_full_equals_n_times_rep_at_scale():
     a = float(mf.loss())
     b = int(mr.n) * float(mr.loss())
     assert abs(a - b) <= 1e-9 * abs(a), (a, b)
+
+
+def test_fit_trajectory_matches_oracle_fit_full_path():
+    """Same L-BFGS-B, same objective: the fitted parameters of the HIP path and of the CPU oracle coincide."""
+    x, y = synth.make_full(61, 120, 2, 4, 3)
+    m = LCGP(y=y, x=x, q=3)
+    o = orc.OracleLCGP(y=y, x=x, q=3)
+    o.phi = m.phi.numpy().copy()
+    m.fit()
+    o.fit()
+    assert abs(float(m.loss()) - o.loss()) <= 1e-7 * abs(o.loss())
+    for a, b in zip(m.get_param(), o.get_param()):
+        np.testing.assert_allclose(a.numpy(), b, rtol=1e-4, atol=1e-7)
+    x0 = np.random.default_rng(2).uniform(0, 1, (25, 2))
+    for a, b in zip(m.predict(x0), o.predict(x0)):
+        np.testing.assert_allclose(a.numpy(), b, rtol=1e-4, atol=1e-6)

@@ -296,3 +296,25 @@ def test_hot_path_fails_loudly_without_gpu():
         Matern32(x, x, np.ones(2), 1.0, 1e-3)
     with pytest.raises(AssertionError):
         Matern32(np.linspace(0, 1, 5), np.linspace(0, 1, 5), 1.0, 1.0, -12.0)
+
+
+def test_drop_in_import_shim_and_metrics():
+    import lcgp
+    from lcgp.covmat import Matern32 as M32
+    from lcgp.lcgp import LCGP as L2
+    from lcgp import evaluation
+    from lcgp_amd import Matern32
+    assert lcgp.__all__ == ['LCGP', 'Matern32', 'test'] and lcgp.LCGP is LCGP and L2 is LCGP and M32 is Matern32
+    rng = np.random.default_rng(0)
+    y = rng.standard_normal((3, 50))
+    m = y + 0.1 * rng.standard_normal((3, 50))
+    v = np.full((3, 50), 0.01)
+    assert abs(evaluation.rmse(y, y)) == 0.0
+    assert abs(evaluation.rmse(y, m) - orc.rmse(y, m)) < 1e-15
+    assert abs(evaluation.normalized_rmse(y, m) - orc.normalized_rmse(y, m)) < 1e-15
+    c1, w1 = evaluation.intervalstats(y, m, v)
+    c2, w2 = orc.intervalstats(y, m, v)
+    assert abs(c1 - c2) < 1e-15 and abs(w1 - w2) < 1e-15 and 0 <= c1 <= 1
+    assert abs(evaluation.dss(y, m, v, use_diag=True) - orc.dss_diag(y, m, v)) < 1e-12
+    cov = np.stack([np.diag(v[:, i]) for i in range(50)], axis=2)
+    assert abs(evaluation.dss(y, m, cov, use_diag=False) - evaluation.dss(y, m, v, use_diag=True)) < 1e-10
