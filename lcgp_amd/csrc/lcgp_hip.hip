@@ -589,19 +589,7 @@ __global__ __launch_bounds__(NW * 64, TM == 128 ? (NW == 8 ? 4 : 2) : 4) void ti
 
     constexpr int SPT = TM / KT;   // stages per k tile
     const int nst = nkt * SPT;
-    T ra[EPT], rb[EPT];
-    load_stage<T, LA, TM, NT>(A0, g.ldA, 0, ra, tid);
-    load_stage<T, LB, TM, NT>(B0, g.ldB, 0, rb, tid);
-    for (int s = 0; s < nst; ++s) {
-        const int buf = s & 1;
-        store_stage<T, LA, TM, NT>(As[buf], ra, tid);
-        store_stage<T, LB, TM, NT>(Bs[buf], rb, tid);
-        __syncthreads();
-        if (s + 1 < nst) {
-            const int kt = (s + 1) / SPT, ks = ((s + 1) % SPT) * KT;
-            load_stage<T, LA, TM, NT>(A0 + (ptrdiff_t)kt * dA, g.ldA, ks, ra, tid);
-            load_stage<T, LB, TM, NT>(B0 + (ptrdiff_t)kt * dB, g.ldB, ks, rb, tid);
-        }
+    auto compute_stage = [&](int buf) {
         const T* as = As[buf];
         const T* bs = Bs[buf];
 #pragma unroll
@@ -619,6 +607,44 @@ __global__ __launch_bounds__(NW * 64, TM == 128 ? (NW == 8 ? 4 : 2) : 4) void ti
             for (int i = 0; i < MIM; ++i)
 #pragma unroll
                 for (int j = 0; j < MIN; ++j) acc[i][j] = Mfma<T>::run(af[i], bf[j], acc[i][j]);
+        }
+    };
+    bool done = false;
+    if constexpr (TM == 64) {
+        // K = 64 (panel TRMM, rank-64 panel update): these launches are one or two rounds of tiles and their time
+        // is the latency of ONE tile -- fetch all four stages up front (one memory latency instead of four)
+        if (nkt == 1) {
+            T pa[SPT][EPT], pb[SPT][EPT];
+#pragma unroll
+            for (int s = 0; s < SPT; ++s) {
+                load_stage<T, LA, TM, NT>(A0, g.ldA, s * KT, pa[s], tid);
+                load_stage<T, LB, TM, NT>(B0, g.ldB, s * KT, pb[s], tid);
+            }
+#pragma unroll
+            for (int s = 0; s < SPT; ++s) {
+                store_stage<T, LA, TM, NT>(As[s & 1], pa[s], tid);
+                store_stage<T, LB, TM, NT>(Bs[s & 1], pb[s], tid);
+                __syncthreads();
+                compute_stage(s & 1);
+            }
+            done = true;
+        }
+    }
+    if (!done) {
+        T ra[EPT], rb[EPT];
+        load_stage<T, LA, TM, NT>(A0, g.ldA, 0, ra, tid);
+        load_stage<T, LB, TM, NT>(B0, g.ldB, 0, rb, tid);
+        for (int s = 0; s < nst; ++s) {
+            const int buf = s & 1;
+            store_stage<T, LA, TM, NT>(As[buf], ra, tid);
+            store_stage<T, LB, TM, NT>(Bs[buf], rb, tid);
+            __syncthreads();
+            if (s + 1 < nst) {
+                const int kt = (s + 1) / SPT, ks = ((s + 1) % SPT) * KT;
+                load_stage<T, LA, TM, NT>(A0 + (ptrdiff_t)kt * dA, g.ldA, ks, ra, tid);
+                load_stage<T, LB, TM, NT>(B0 + (ptrdiff_t)kt * dB, g.ldB, ks, rb, tid);
+            }
+            compute_stage(buf);
         }
     }
     // (the panel TRMM overwrites its own A tile: all of it went through LDS before the last barrier)
