@@ -939,12 +939,19 @@ int do_build(hipStream_t st, const Ws& w, const void* x, const void* sr, const d
     return 0;
 }
 
+int g_waves128 = 8;       // experiment (lcgp_set_tuning key 9): 4 = 128x128 tiles with 4 waves x (4x4) accumulators
+
 template <typename T, int OP, int TM = TS>
 int launch_gemm(hipStream_t st, const GemmArgs& g, int ntiles, int q) {
     if (ntiles <= 0) return 0;
     constexpr int NW = TM == 128 ? 8 : 4;
     GemmArgs h = g;
     h.q = q;
+    if (TM == 128 && g_waves128 == 4) {
+        hipLaunchKernelGGL((tile_gemm<T, OP, TM, 4>), dim3((unsigned)ntiles * q), dim3(256), 0, st, h);
+        CHECK_LAUNCH("tile_gemm");
+        return 0;
+    }
     hipLaunchKernelGGL((tile_gemm<T, OP, TM, NW>), dim3((unsigned)ntiles * q), dim3(NW * 64), 0, st, h);
     CHECK_LAUNCH("tile_gemm");
     return 0;
@@ -1409,6 +1416,10 @@ int lcgp_set_tuning(int key, int value) {
     }
     if (key == 7) {
         g_small_tiles_lauum = value;
+        return 0;
+    }
+    if (key == 9) {
+        g_waves128 = value == 4 ? 4 : 8;
         return 0;
     }
     if (key == 8) {
