@@ -12,6 +12,7 @@
 // the padding is the identity so every kernel works on whole 64x64 tiles):
 //   M : A, then L (lower tiles)      W : L^-1 (lower tiles)      V : scratch, then A^-1 (lower tiles)
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <string.h>
@@ -1022,6 +1023,7 @@ inline int trapezoid_tiles(int nb, int c_lo, int c_hi) {
 // is touched once per outer panel with K = 64 * g_outer_blocks (read-modify-write traffic / g_outer_blocks).
 int g_chain_prio = 0;     // lcgp_set_tuning key 4: 1 = create the chain stream with the highest priority (before first use)
 int g_small_tiles_syrk = 768;   // lcgp_set_tuning key 8
+int g_any_order = 0;      // lcgp_set_tuning key 10: launch the first diagonal block of a panel without the barrier bit
 int g_lookahead = 0;      // lcgp_set_tuning key 3: 1 = panel chain on its own stream ahead of the trailing update.
                           // OFF by default: measured on MI355X / ROCm 7.2, as soon as one HIP stream waits on another
                           // (barrier packet) every kernel boundary on the running stream costs 20-40 us, so the
@@ -1043,8 +1045,16 @@ int potrf_panel(hipStream_t st, const Ws& w, int J, int pe) {
     GemmArgs g;
     g.sA = g.sB = g.sC = w.mat; g.ldA = g.ldB = g.ldC = w.npad; g.nb = w.nb;
     for (int c = J; c < pe; ++c) {
-        hipLaunchKernelGGL((leaf_kernel<T>), dim3(w.q), dim3(256), 0, st, M, W, w.mat, w.npad, c, logdet, info,
-                           g_debug_mask);
+        if (c == J && J > 0 && g_any_order) {
+            // the first diagonal block of a panel depends on the FIRST slice of the previous trailing update only
+            // (its own columns); that slice completed before the second slice was even dispatched, so this launch
+            // may start while the second slice drains (no barrier bit): it fills the tail of the wide launch
+            hipExtLaunchKernelGGL((leaf_kernel<T>), dim3(w.q), dim3(256), 0, st, nullptr, nullptr, hipExtAnyOrderLaunch,
+                                  M, W, w.mat, w.npad, c, logdet, info, g_debug_mask);
+        } else {
+            hipLaunchKernelGGL((leaf_kernel<T>), dim3(w.q), dim3(256), 0, st, M, W, w.mat, w.npad, c, logdet, info,
+                               g_debug_mask);
+        }
         CHECK_LAUNCH("leaf_kernel");
         if (c + 1 >= w.nb) break;
         g.A = M; g.B = W; g.C = M; g.p0 = c; g.p1 = g.p2 = g.p3 = 0;
@@ -1102,7 +1112,13 @@ int do_potrf(hipStream_t st, const Ws& w) {
                 const int pe = J + ob < se ? J + ob : se;
                 int rc = potrf_panel<T>(st, w, J, pe);
                 if (rc) return rc;
-                rc = potrf_trailing<T>(st, w, J, pe, pe, se, t128);
+                if (g_any_order && pe + ob < se) {
+                    rc = potrf_trailing<T>(st, w, J, pe, pe, pe + ob, t128);      // columns of the next panel first
+                    if (rc) return rc;
+                    rc = potrf_trailing<T>(st, w, J, pe, pe + ob, se, t128);
+                } else {
+                    rc = potrf_trailing<T>(st, w, J, pe, pe, se, t128);
+                }
                 if (rc) return rc;
             }
             int rc = potrf_trailing<T>(st, w, S, se, se, w.nb, t128);
@@ -1416,6 +1432,10 @@ int lcgp_set_tuning(int key, int value) {
     }
     if (key == 7) {
         g_small_tiles_lauum = value;
+        return 0;
+    }
+    if (key == 10) {
+        g_any_order = value ? 1 : 0;
         return 0;
     }
     if (key == 9) {
