@@ -304,14 +304,15 @@ __device__ __forceinline__ void leaf_pivot_group(double (&r)[16], double (*colbu
     }
 }
 
+constexpr int LEAF_LDS_BYTES = (2 * 2 * TS + TS + 2 * TS * (TS + 1)) * 8;   // colbuf + dinv + a + w = 69,120 B
+
 template <typename T>
-__global__ __launch_bounds__(256) void leaf_kernel(T* __restrict__ M, T* __restrict__ W, size_t mat, int npad, int jb,
-                                                   double* __restrict__ logdet, int* __restrict__ info, int dbg) {
-    __shared__ double colbuf[2][2][TS];
-    __shared__ double dinv[TS];
-    __shared__ double a[TS][TS + 1];
-    __shared__ double w[TS][TS + 1];
-    const int k = blockIdx.x;
+__device__ __forceinline__ void leaf_body(unsigned char* lds, int k, T* __restrict__ M, T* __restrict__ W, size_t mat,
+                                          int npad, int jb, double* __restrict__ logdet, int* __restrict__ info, int dbg) {
+    double (*colbuf)[2][TS] = (double (*)[2][TS])lds;
+    double* dinv = (double*)(lds + 2 * 2 * TS * 8);
+    double (*a)[TS + 1] = (double (*)[TS + 1])(lds + (2 * 2 * TS + TS) * 8);
+    double (*w)[TS + 1] = (double (*)[TS + 1])(lds + (2 * 2 * TS + TS + TS * (TS + 1)) * 8);
     const int tid = threadIdx.x;
     T* Mb = M + (size_t)k * mat + (size_t)jb * TS * npad + (size_t)jb * TS;
     T* Wb = W + (size_t)k * mat + (size_t)jb * TS * npad + (size_t)jb * TS;
@@ -405,6 +406,13 @@ __global__ __launch_bounds__(256) void leaf_kernel(T* __restrict__ M, T* __restr
     }
 }
 
+template <typename T>
+__global__ __launch_bounds__(256) void leaf_kernel(T* __restrict__ M, T* __restrict__ W, size_t mat, int npad, int jb,
+                                                   double* __restrict__ logdet, int* __restrict__ info, int dbg) {
+    __shared__ __align__(16) unsigned char lds[LEAF_LDS_BYTES];
+    leaf_body<T>(lds, blockIdx.x, M, W, mat, npad, jb, logdet, info, dbg);
+}
+
 // ---------------------------------------------------------------------------------------------------
 // Tile GEMM on MFMA:  C_tile (op)= alpha * sum_kt  Aop(kt) * Bop(kt)^T,   64x64 output per workgroup,
 // 4 waves each owning a 32x32 quadrant (2x2 MFMA 16x16x4 accumulators).  Operand tiles are 64 x 64
@@ -422,6 +430,7 @@ struct GemmArgs {
     int nb;                                     // number of 64-blocks
     int p0, p1, p2, p3;                         // op specific
     int q;                                      // components in this launch
+    int t0;                                     // first tile of this launch (OP_SYRK: a launch may cover a sub-range)
 };
 
 // one K-stage (KT = 16 k values) of a TM-row operand tile: global -> registers -> LDS [k][m], ld = TM + 16;
@@ -475,7 +484,8 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 //                     operand traffic per flop of the 64-tile
 // All tile coordinates (g.nb, g.p0..p3) are in units of TM.
 template <typename T, int OP, int TM, int NW>
-__global__ __launch_bounds__(NW * 64, TM == 128 ? (NW == 8 ? 4 : 2) : 4) void tile_gemm(GemmArgs g) {
+__device__ __forceinline__ void gemm_body(const GemmArgs& g, const int lin /*block index within this descriptor*/,
+                                          unsigned char* lds) {
     constexpr int LA = (OP == OP_LAUUM) ? KM : MK;
     constexpr int LB = (OP == OP_TRTRI_T || OP == OP_TRTRI_W || OP == OP_LAUUM) ? KM : MK;
     constexpr int NT = NW * 64;
@@ -483,14 +493,13 @@ __global__ __launch_bounds__(NW * 64, TM == 128 ? (NW == 8 ? 4 : 2) : 4) void ti
     constexpr int WTM = TM / (NW / 2), WTN = TM / 2;   // per-wave sub-tile
     constexpr int MIM = WTM / 16, MIN = WTN / 16;      // MFMA tiles per wave
     constexpr int EPT = TM * KT / NT;
-    __shared__ T As[2][KT * LD];
-    __shared__ T Bs[2][KT * LD];
+    T* As = (T*)lds;                  // [2][KT * LD]
+    T* Bs = As + 2 * KT * LD;         // [2][KT * LD]
 
-    // 1-D grid over (tile, component) with the component as the FAST index: tiles are enumerated heaviest first,
-    // so the heaviest tiles of every component start at once instead of component by component
-    const int k = blockIdx.x % g.q;
-    const int bid = blockIdx.x / g.q;
-    const int ntile = gridDim.x / g.q;
+    // (tile, component) with the component as the FAST index: tiles are enumerated heaviest first, so the heaviest
+    // tiles of every component start at once instead of component by component
+    const int k = lin % g.q;
+    const int bid = lin / g.q;
     const T* Ab = (const T*)g.A + (size_t)k * g.sA;
     const T* Bb = (const T*)g.B + (size_t)k * g.sB;
     T* Cb = (T*)g.C + (size_t)k * g.sC;
@@ -511,7 +520,7 @@ __global__ __launch_bounds__(NW * 64, TM == 128 ? (NW == 8 ? 4 : 2) : 4) void ti
     } else if constexpr (OP == OP_SYRK) {
         // M[r, c] -= sum_{kt in [p0, p1)} M[r, kt] M[c, kt]^T over the tiles c in [p2, p3), r in [c, nb)
         // (p3 == nb: the whole trailing triangle; p3 < nb: the rest of the current panel), column-major
-        int t = bid, c = g.p2;
+        int t = bid + g.t0, c = g.p2;
         while (t >= g.nb - c) { t -= g.nb - c; ++c; }
         const int r = c + t;
         A0 = Ab + (size_t)r * TM * g.ldA + (size_t)g.p0 * TM; dA = TM;
@@ -591,8 +600,8 @@ __global__ __launch_bounds__(NW * 64, TM == 128 ? (NW == 8 ? 4 : 2) : 4) void ti
     constexpr int SPT = TM / KT;   // stages per k tile
     const int nst = nkt * SPT;
     auto compute_stage = [&](int buf) {
-        const T* as = As[buf];
-        const T* bs = Bs[buf];
+        const T* as = As + buf * KT * LD;
+        const T* bs = Bs + buf * KT * LD;
 #pragma unroll
         for (int kk = 0; kk < KT / 4; ++kk) {
             const int krow = (kk * 4 + (lane >> 4)) * LD;
@@ -623,8 +632,8 @@ __global__ __launch_bounds__(NW * 64, TM == 128 ? (NW == 8 ? 4 : 2) : 4) void ti
             }
 #pragma unroll
             for (int s = 0; s < SPT; ++s) {
-                store_stage<T, LA, TM, NT>(As[s & 1], pa[s], tid);
-                store_stage<T, LB, TM, NT>(Bs[s & 1], pb[s], tid);
+                store_stage<T, LA, TM, NT>(As + (s & 1) * KT * LD, pa[s], tid);
+                store_stage<T, LB, TM, NT>(Bs + (s & 1) * KT * LD, pb[s], tid);
                 __syncthreads();
                 compute_stage(s & 1);
             }
@@ -632,20 +641,31 @@ __global__ __launch_bounds__(NW * 64, TM == 128 ? (NW == 8 ? 4 : 2) : 4) void ti
         }
     }
     if (!done) {
-        T ra[EPT], rb[EPT];
-        load_stage<T, LA, TM, NT>(A0, g.ldA, 0, ra, tid);
-        load_stage<T, LB, TM, NT>(B0, g.ldB, 0, rb, tid);
-        for (int s = 0; s < nst; ++s) {
-            const int buf = s & 1;
-            store_stage<T, LA, TM, NT>(As[buf], ra, tid);
-            store_stage<T, LB, TM, NT>(Bs[buf], rb, tid);
-            __syncthreads();
-            if (s + 1 < nst) {
-                const int kt = (s + 1) / SPT, ks = ((s + 1) % SPT) * KT;
-                load_stage<T, LA, TM, NT>(A0 + (ptrdiff_t)kt * dA, g.ldA, ks, ra, tid);
-                load_stage<T, LB, TM, NT>(B0 + (ptrdiff_t)kt * dB, g.ldB, ks, rb, tid);
+        // register prefetch TWO stages ahead (the loads of stage s+2 are issued while stage s is multiplied): with
+        // few workgroups per CU one stage of MFMAs (~0.5 us) does not cover an HBM/L2 round trip
+        T ra[2][EPT], rb[2][EPT];
+        load_stage<T, LA, TM, NT>(A0, g.ldA, 0, ra[0], tid);
+        load_stage<T, LB, TM, NT>(B0, g.ldB, 0, rb[0], tid);
+        if (nst > 1) {
+            const int kt = 1 / SPT, ks = (1 % SPT) * KT;
+            load_stage<T, LA, TM, NT>(A0 + (ptrdiff_t)kt * dA, g.ldA, ks, ra[1], tid);
+            load_stage<T, LB, TM, NT>(B0 + (ptrdiff_t)kt * dB, g.ldB, ks, rb[1], tid);
+        }
+        for (int s = 0; s < nst; s += 2) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {        // h = (s + h) & 1: static register / buffer index
+                if (s + h < nst) {
+                    store_stage<T, LA, TM, NT>(As + h * KT * LD, ra[h], tid);
+                    store_stage<T, LB, TM, NT>(Bs + h * KT * LD, rb[h], tid);
+                    __syncthreads();
+                    if (s + h + 2 < nst) {
+                        const int kt = (s + h + 2) / SPT, ks = ((s + h + 2) % SPT) * KT;
+                        load_stage<T, LA, TM, NT>(A0 + (ptrdiff_t)kt * dA, g.ldA, ks, ra[h], tid);
+                        load_stage<T, LB, TM, NT>(B0 + (ptrdiff_t)kt * dB, g.ldB, ks, rb[h], tid);
+                    }
+                    compute_stage(h);
+                }
             }
-            compute_stage(buf);
         }
     }
     // (the panel TRMM overwrites its own A tile: all of it went through LDS before the last barrier)
@@ -666,6 +686,34 @@ __global__ __launch_bounds__(NW * 64, TM == 128 ? (NW == 8 ? 4 : 2) : 4) void ti
                     *dst = (T)v;
                 }
             }
+}
+
+template <typename T, int OP, int TM, int NW>
+__global__ __launch_bounds__(NW * 64, TM == 128 ? (NW == 8 ? 4 : 2) : 4) void tile_gemm(GemmArgs g) {
+    __shared__ __align__(16) unsigned char lds[4 * KT * (TM + 16) * sizeof(T)];
+    gemm_body<T, OP, TM, NW>(g, blockIdx.x, lds);
+}
+
+// Heterogeneous launches.  The panel chain of the Cholesky (diagonal block -> panel TRMM -> panel update, 64 times)
+// is a sequence of small dependent launches that leave most CUs idle, and two HIP streams cannot overlap them with
+// the wide trailing update on this platform.  So the chain launches CARRY independent work: blocks
+// beyond the chain's own are "filler" tiles of the previous panel's trailing update (64x64 tiles, K = panel width),
+// which touch columns the chain of the current panel neither reads nor writes.  No inter-workgroup dependency
+// exists inside such a launch; stream order between launches provides all the ordering.
+template <typename T, int OP>
+__global__ __launch_bounds__(256, 4) void tile_gemm_fill(GemmArgs g, GemmArgs f, int nprim) {
+    __shared__ __align__(16) unsigned char lds[4 * KT * (TS + 16) * sizeof(T)];
+    if ((int)blockIdx.x < nprim) gemm_body<T, OP, TS, 4>(g, blockIdx.x, lds);
+    else gemm_body<T, OP_SYRK, TS, 4>(f, blockIdx.x - nprim, lds);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void leaf_fill_kernel(T* __restrict__ M, T* __restrict__ W, size_t mat, int npad, int jb,
+                                                        double* __restrict__ logdet, int* __restrict__ info, int dbg,
+                                                        int q, GemmArgs f) {
+    __shared__ __align__(16) unsigned char lds[LEAF_LDS_BYTES];
+    if ((int)blockIdx.x < q) leaf_body<T>(lds, blockIdx.x, M, W, mat, npad, jb, logdet, info, dbg);
+    else gemm_body<T, OP_SYRK, TS, 4>(f, blockIdx.x - q, lds);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -948,6 +996,7 @@ int launch_gemm(hipStream_t st, const GemmArgs& g, int ntiles, int q) {
     constexpr int NW = TM == 128 ? 8 : 4;
     GemmArgs h = g;
     h.q = q;
+    h.t0 = 0;
     if (TM == 128 && g_waves128 == 4) {
         hipLaunchKernelGGL((tile_gemm<T, OP, TM, 4>), dim3((unsigned)ntiles * q), dim3(256), 0, st, h);
         CHECK_LAUNCH("tile_gemm");
@@ -1035,20 +1084,44 @@ int g_lookahead = 0;      // lcgp_set_tuning key 3: 1 = panel chain on its own s
         if (e__ != hipSuccess) return fail(what, e__);      \
     } while (0)
 
-// one outer panel [J, pe): per 64-column step  diagonal block -> panel TRMM -> rank-64 update of the rest of the panel
+// Filler work carried by the chain launches: a range of 64x64 tiles of a trailing update (see tile_gemm_fill).
+struct Filler {
+    GemmArgs f;          // OP_SYRK on 64-tiles; f.q set
+    long next = 0;       // next tile (trapezoid enumeration over columns [f.p2, f.p3))
+    long total = 0;
+    bool active() const { return next < total; }
+    // reserves up to `cap_blocks` blocks (= tiles x components); returns the block count and fills `out`
+    int take(int cap_blocks, GemmArgs& out) {
+        if (!active() || cap_blocks < f.q) return 0;
+        long n = cap_blocks / f.q;
+        if (n > total - next) n = total - next;
+        out = f;
+        out.t0 = (int)next;
+        next += n;
+        return (int)n * f.q;
+    }
+};
+
+int g_fill_leaf = 496;    // filler blocks carried by a diagonal-block launch   (lcgp_set_tuning key 11; 0 = off)
+int g_fill_small = 0;     // filler blocks carried by a panel TRMM / panel update launch (key 12; measured: they only
+                          // lengthen those 7-13 us launches)
+
+// one outer panel [J, pe): per 64-column step  diagonal block -> panel TRMM -> rank-64 update of the rest of the panel;
+// every launch may carry filler tiles
 template <typename T>
-int potrf_panel(hipStream_t st, const Ws& w, int J, int pe) {
+int potrf_panel(hipStream_t st, const Ws& w, int J, int pe, Filler* fill = nullptr) {
     T* M = (T*)(w.base + w.off_M);
     T* W = (T*)(w.base + w.off_W);
     double* logdet = (double*)(w.base + w.off_logdet);
     int* info = (int*)(w.base + w.off_info);
-    GemmArgs g;
-    g.sA = g.sB = g.sC = w.mat; g.ldA = g.ldB = g.ldC = w.npad; g.nb = w.nb;
+    GemmArgs g, fa;
+    g.sA = g.sB = g.sC = w.mat; g.ldA = g.ldB = g.ldC = w.npad; g.nb = w.nb; g.q = w.q; g.t0 = 0;
     for (int c = J; c < pe; ++c) {
-        if (c == J && J > 0 && g_any_order) {
-            // the first diagonal block of a panel depends on the FIRST slice of the previous trailing update only
-            // (its own columns); that slice completed before the second slice was even dispatched, so this launch
-            // may start while the second slice drains (no barrier bit): it fills the tail of the wide launch
+        int nf = fill ? fill->take(g_fill_leaf, fa) : 0;
+        if (nf > 0) {
+            hipLaunchKernelGGL((leaf_fill_kernel<T>), dim3(w.q + nf), dim3(256), 0, st, M, W, w.mat, w.npad, c, logdet, info,
+                               g_debug_mask, w.q, fa);
+        } else if (c == J && J > 0 && g_any_order) {
             hipExtLaunchKernelGGL((leaf_kernel<T>), dim3(w.q), dim3(256), 0, st, nullptr, nullptr, hipExtAnyOrderLaunch,
                                   M, W, w.mat, w.npad, c, logdet, info, g_debug_mask);
         } else {
@@ -1058,13 +1131,36 @@ int potrf_panel(hipStream_t st, const Ws& w, int J, int pe) {
         CHECK_LAUNCH("leaf_kernel");
         if (c + 1 >= w.nb) break;
         g.A = M; g.B = W; g.C = M; g.p0 = c; g.p1 = g.p2 = g.p3 = 0;
-        int rc = launch_gemm<T, OP_TRMM_PANEL>(st, g, w.nb - 1 - c, w.q);
-        if (rc) return rc;
-        if (c + 1 < pe) {
-            g.A = M; g.B = M; g.C = M; g.p0 = c; g.p1 = c + 1; g.p2 = c + 1; g.p3 = pe;
-            rc = launch_gemm<T, OP_SYRK>(st, g, trapezoid_tiles(w.nb, c + 1, pe), w.q);
+        nf = fill ? fill->take(g_fill_small, fa) : 0;
+        if (nf > 0) {
+            const int np = (w.nb - 1 - c) * w.q;
+            hipLaunchKernelGGL((tile_gemm_fill<T, OP_TRMM_PANEL>), dim3(np + nf), dim3(256), 0, st, g, fa, np);
+            CHECK_LAUNCH("tile_gemm_fill");
+        } else {
+            int rc = launch_gemm<T, OP_TRMM_PANEL>(st, g, w.nb - 1 - c, w.q);
             if (rc) return rc;
         }
+        if (c + 1 < pe) {
+            g.A = M; g.B = M; g.C = M; g.p0 = c; g.p1 = c + 1; g.p2 = c + 1; g.p3 = pe;
+            nf = fill ? fill->take(g_fill_small, fa) : 0;
+            if (nf > 0) {
+                const int np = trapezoid_tiles(w.nb, c + 1, pe) * w.q;
+                hipLaunchKernelGGL((tile_gemm_fill<T, OP_SYRK>), dim3(np + nf), dim3(256), 0, st, g, fa, np);
+                CHECK_LAUNCH("tile_gemm_fill");
+            } else {
+                int rc = launch_gemm<T, OP_SYRK>(st, g, trapezoid_tiles(w.nb, c + 1, pe), w.q);
+                if (rc) return rc;
+            }
+        }
+    }
+    // whatever the chain could not carry runs as one plain launch
+    if (fill && fill->active()) {
+        GemmArgs rest = fill->f;
+        rest.t0 = (int)fill->next;
+        const long n = fill->total - fill->next;
+        fill->next = fill->total;
+        hipLaunchKernelGGL((tile_gemm<T, OP_SYRK, TS, 4>), dim3((unsigned)(n * w.q)), dim3(256), 0, st, rest);
+        CHECK_LAUNCH("tile_gemm");
     }
     return 0;
 }
@@ -1101,24 +1197,49 @@ int do_potrf(hipStream_t st, const Ws& w) {
     const int ob = g_outer_blocks < 1 ? 1 : g_outer_blocks;
     const bool t128 = (ob & 1) == 0;
     if (!g_lookahead || w.nb <= ob) {
-        // three levels: 64-column steps inside a panel of `ob` blocks, panels inside a super-panel of `sb` blocks
-        // (their trailing updates stop at the super-panel boundary, K = 64 ob), and one far update per super-panel
-        // with K = 64 sb: most flops of the trailing update then run as few long-K launches
         int sb = g_super_blocks < ob ? ob : g_super_blocks;
         sb = sb / ob * ob;
+        if (sb == ob) {
+            // Two-level schedule with filler: the trailing update of panel J is split by columns into one wide
+            // 128x128-tile launch (the columns of panel J+1 and as many more as do not fit below) and the right-most
+            // columns, which the chain launches of panel J+1 carry as filler tiles (as many as those launches can
+            // hide: g_fill_leaf / g_fill_small blocks each).
+            Filler fill;
+            const int per_panel_blocks = ob * g_fill_leaf + (2 * ob - 1) * g_fill_small;
+            for (int J = 0; J < w.nb; J += ob) {
+                const int pe = J + ob < w.nb ? J + ob : w.nb;
+                int rc = potrf_panel<T>(st, w, J, pe, fill.active() ? &fill : nullptr);
+                if (rc) return rc;
+                if (pe >= w.nb) break;
+                const int mid = pe + ob < w.nb ? pe + ob : w.nb;     // the next panel's own columns are never filler
+                int cf = w.nb;                                         // first filler column
+                if (t128 && per_panel_blocks >= w.q && mid < w.nb) {
+                    const long cap_tiles = per_panel_blocks / w.q;
+                    while (cf - 2 >= mid && trapezoid_tiles(w.nb, cf - 2, w.nb) <= cap_tiles) cf -= 2;
+                }
+                rc = potrf_trailing<T>(st, w, J, pe, pe, cf, t128);                    // one wide launch
+                if (rc) return rc;
+                fill = Filler();
+                if (cf < w.nb) {                                                       // U2b
+                    GemmArgs& f = fill.f;
+                    f.A = w.base + w.off_M; f.B = f.A; f.C = (void*)f.A;
+                    f.sA = f.sB = f.sC = w.mat; f.ldA = f.ldB = f.ldC = w.npad; f.nb = w.nb;
+                    f.p0 = J; f.p1 = pe; f.p2 = cf; f.p3 = w.nb; f.q = w.q; f.t0 = 0;
+                    fill.total = trapezoid_tiles(w.nb, cf, w.nb);
+                }
+            }
+            return 0;
+        }
+        // three levels: 64-column steps inside a panel of `ob` blocks, panels inside a super-panel of `sb` blocks
+        // (their trailing updates stop at the super-panel boundary, K = 64 ob), and one far update per super-panel
+        // with K = 64 sb (measured: not faster than two levels)
         for (int S = 0; S < w.nb; S += sb) {
             const int se = S + sb < w.nb ? S + sb : w.nb;
             for (int J = S; J < se; J += ob) {
                 const int pe = J + ob < se ? J + ob : se;
                 int rc = potrf_panel<T>(st, w, J, pe);
                 if (rc) return rc;
-                if (g_any_order && pe + ob < se) {
-                    rc = potrf_trailing<T>(st, w, J, pe, pe, pe + ob, t128);      // columns of the next panel first
-                    if (rc) return rc;
-                    rc = potrf_trailing<T>(st, w, J, pe, pe + ob, se, t128);
-                } else {
-                    rc = potrf_trailing<T>(st, w, J, pe, pe, se, t128);
-                }
+                rc = potrf_trailing<T>(st, w, J, pe, pe, se, t128);
                 if (rc) return rc;
             }
             int rc = potrf_trailing<T>(st, w, S, se, se, w.nb, t128);
@@ -1432,6 +1553,14 @@ int lcgp_set_tuning(int key, int value) {
     }
     if (key == 7) {
         g_small_tiles_lauum = value;
+        return 0;
+    }
+    if (key == 11) {
+        g_fill_leaf = value;
+        return 0;
+    }
+    if (key == 12) {
+        g_fill_small = value;
         return 0;
     }
     if (key == 10) {
