@@ -60,7 +60,7 @@ int lcgp_out_width(int d, int p);
  *          its longest tile (0 = always 128x128);
  *   key 8: the same switch for the trailing update of the Cholesky (default 768);
  *   key 11 / key 12: filler blocks (64x64 tiles of the previous panel's trailing update) carried by each diagonal-block
- *          launch (11, default 496) / each panel TRMM or panel update launch (12, default 0); 0 = no filler;
+ *          launch (11, default 248; 128x64 tiles) ; key 12 is unused; 0 = no filler;
  *   key 3: 1 = look-ahead Cholesky (panel chain on an internal stream), 0 (default) = single stream;
  *   key 4: 1 = create that internal stream with the highest priority;
  *   key 1: number of component groups whose factorisation chains run on internal streams (default 1 = off, max 8). */

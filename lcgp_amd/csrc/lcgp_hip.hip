@@ -694,6 +694,89 @@ __global__ __launch_bounds__(NW * 64, TM == 128 ? (NW == 8 ? 4 : 2) : 4) void ti
     gemm_body<T, OP, TM, NW>(g, blockIdx.x, lds);
 }
 
+// Rectangular variant of the trailing update for FILLER work: 128 x 64 tiles on 4 waves (64 x 32 per wave, 4x2
+// accumulators).  A filler workgroup shares its launch with the diagonal-block kernel, i.e. 256 threads and two
+// workgroups per CU; a 64x64 tile then leaves the MFMA pipe half idle, this shape fills it (same K loop, twice
+// the flops per workgroup, 57 KB of LDS).  Tiles: 64-wide column c (from g.p2 to g.nb, 64-units), 128-row blocks R
+// from c/2 down to the last; K = the 64-blocks [g.p0, g.p1).  C -= A B^T with C preloaded into the accumulators.
+template <typename T>
+__device__ __forceinline__ void syrk_rect_body(const GemmArgs& g, const int lin, unsigned char* lds) {
+    constexpr int TMR = 128, TNC = 64, NT = 256;
+    constexpr int LDA = TMR + 16, LDB = TNC + 16;
+    constexpr int EA = TMR * KT / NT, EB = TNC * KT / NT;
+    T* As = (T*)lds;                   // [2][KT * LDA]
+    T* Bs = As + 2 * KT * LDA;         // [2][KT * LDB]
+    const int k = lin % g.q;
+    int t = lin / g.q + g.t0, c = g.p2;
+    const int nb2 = g.nb / 2;
+    while (t >= nb2 - (c >> 1)) { t -= nb2 - (c >> 1); ++c; }
+    const int R = (c >> 1) + t;
+    const T* A0 = (const T*)g.A + (size_t)k * g.sA + (size_t)R * TMR * g.ldA + (size_t)g.p0 * TS;
+    const T* B0 = (const T*)g.B + (size_t)k * g.sB + (size_t)c * TNC * g.ldB + (size_t)g.p0 * TS;
+    T* Ct = (T*)g.C + (size_t)k * g.sC + (size_t)R * TMR * g.ldC + (size_t)c * TNC;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm0 = (wave >> 1) * 64, wn0 = (wave & 1) * 32;
+    typedef typename Mfma<T>::acc_t acc_t;
+    acc_t acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                acc[i][j][e] = Ct[(size_t)(wm0 + i * 16 + Mfma<T>::row(lane, e)) * g.ldC + wn0 + j * 16 + (lane & 15)];
+    const int nst = (g.p1 - g.p0) * (TS / KT);
+    T ra[2][EA], rb[2][EB];
+    load_stage<T, MK, TMR, NT>(A0, g.ldA, 0, ra[0], tid);
+    load_stage<T, MK, TNC, NT>(B0, g.ldB, 0, rb[0], tid);
+    if (nst > 1) {
+        load_stage<T, MK, TMR, NT>(A0, g.ldA, KT, ra[1], tid);
+        load_stage<T, MK, TNC, NT>(B0, g.ldB, KT, rb[1], tid);
+    }
+    for (int s = 0; s < nst; s += 2) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            if (s + h < nst) {
+                store_stage<T, MK, TMR, NT>(As + h * KT * LDA, ra[h], tid);
+                store_stage<T, MK, TNC, NT>(Bs + h * KT * LDB, rb[h], tid);
+                __syncthreads();
+                if (s + h + 2 < nst) {
+                    load_stage<T, MK, TMR, NT>(A0, g.ldA, (s + h + 2) * KT, ra[h], tid);
+                    load_stage<T, MK, TNC, NT>(B0, g.ldB, (s + h + 2) * KT, rb[h], tid);
+                }
+                const T* as = As + h * KT * LDA;
+                const T* bs = Bs + h * KT * LDB;
+#pragma unroll
+                for (int kk = 0; kk < KT / 4; ++kk) {
+                    const int kr = kk * 4 + (lane >> 4);
+                    T af[4], bf[2];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) af[i] = -as[kr * LDA + wm0 + i * 16 + (lane & 15)];
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) bf[j] = bs[kr * LDB + wn0 + j * 16 + (lane & 15)];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) acc[i][j] = Mfma<T>::run(af[i], bf[j], acc[i][j]);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                Ct[(size_t)(wm0 + i * 16 + Mfma<T>::row(lane, e)) * g.ldC + wn0 + j * 16 + (lane & 15)] = acc[i][j][e];
+}
+
+template <typename T>
+__global__ __launch_bounds__(256, 2) void syrk_rect_kernel(GemmArgs g) {
+    __shared__ __align__(16) unsigned char lds[2 * KT * (128 + 16 + 64 + 16) * sizeof(T)];
+    syrk_rect_body<T>(g, blockIdx.x, lds);
+}
+
 // Heterogeneous launches.  The panel chain of the Cholesky (diagonal block -> panel TRMM -> panel update, 64 times)
 // is a sequence of small dependent launches that leave most CUs idle, and two HIP streams cannot overlap them with
 // the wide trailing update on this platform.  So the chain launches CARRY independent work: blocks
@@ -713,7 +796,7 @@ __global__ __launch_bounds__(256) void leaf_fill_kernel(T* __restrict__ M, T* __
                                                         int q, GemmArgs f) {
     __shared__ __align__(16) unsigned char lds[LEAF_LDS_BYTES];
     if ((int)blockIdx.x < q) leaf_body<T>(lds, blockIdx.x, M, W, mat, npad, jb, logdet, info, dbg);
-    else gemm_body<T, OP_SYRK, TS, 4>(f, blockIdx.x - q, lds);
+    else syrk_rect_body<T>(f, blockIdx.x - q, lds);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -1063,6 +1146,13 @@ int g_super_blocks = 0;   // width of the Cholesky super-panel in 64-blocks (lcg
                           // (measured: 8, 16, 32 are not faster at n=4096)
 int g_debug_mask = 0;     // timing experiments only (lcgp_set_tuning key 2): 1 = skip pivots, 2 = skip inverse
 
+// 128 x 64 filler tiles over the 64-columns [c_lo, c_hi): column c has nb/2 - c/2 row blocks
+inline long rect_tiles(int nb, int c_lo, int c_hi) {
+    long n = 0;
+    for (int c = c_lo; c < c_hi; ++c) n += nb / 2 - (c >> 1);
+    return n;
+}
+
 inline int trapezoid_tiles(int nb, int c_lo, int c_hi) {
     return (c_hi - c_lo) * nb - (c_lo + c_hi - 1) * (c_hi - c_lo) / 2;
 }
@@ -1102,7 +1192,9 @@ struct Filler {
     }
 };
 
-int g_fill_leaf = 496;    // filler blocks carried by a diagonal-block launch   (lcgp_set_tuning key 11; 0 = off)
+int g_fill_leaf = 248;    // filler blocks (128x64 tiles) carried by a diagonal-block launch (lcgp_set_tuning key 11; 0 = off):
+                          // one per otherwise idle CU is nearly free (launch 26 -> 30 us), a second one costs what it would
+                          // cost in the wide launch
 int g_fill_small = 0;     // filler blocks carried by a panel TRMM / panel update launch (key 12; measured: they only
                           // lengthen those 7-13 us launches)
 
@@ -1131,26 +1223,12 @@ int potrf_panel(hipStream_t st, const Ws& w, int J, int pe, Filler* fill = nullp
         CHECK_LAUNCH("leaf_kernel");
         if (c + 1 >= w.nb) break;
         g.A = M; g.B = W; g.C = M; g.p0 = c; g.p1 = g.p2 = g.p3 = 0;
-        nf = fill ? fill->take(g_fill_small, fa) : 0;
-        if (nf > 0) {
-            const int np = (w.nb - 1 - c) * w.q;
-            hipLaunchKernelGGL((tile_gemm_fill<T, OP_TRMM_PANEL>), dim3(np + nf), dim3(256), 0, st, g, fa, np);
-            CHECK_LAUNCH("tile_gemm_fill");
-        } else {
-            int rc = launch_gemm<T, OP_TRMM_PANEL>(st, g, w.nb - 1 - c, w.q);
-            if (rc) return rc;
-        }
+        int rc = launch_gemm<T, OP_TRMM_PANEL>(st, g, w.nb - 1 - c, w.q);
+        if (rc) return rc;
         if (c + 1 < pe) {
             g.A = M; g.B = M; g.C = M; g.p0 = c; g.p1 = c + 1; g.p2 = c + 1; g.p3 = pe;
-            nf = fill ? fill->take(g_fill_small, fa) : 0;
-            if (nf > 0) {
-                const int np = trapezoid_tiles(w.nb, c + 1, pe) * w.q;
-                hipLaunchKernelGGL((tile_gemm_fill<T, OP_SYRK>), dim3(np + nf), dim3(256), 0, st, g, fa, np);
-                CHECK_LAUNCH("tile_gemm_fill");
-            } else {
-                int rc = launch_gemm<T, OP_SYRK>(st, g, trapezoid_tiles(w.nb, c + 1, pe), w.q);
-                if (rc) return rc;
-            }
+            rc = launch_gemm<T, OP_SYRK>(st, g, trapezoid_tiles(w.nb, c + 1, pe), w.q);
+            if (rc) return rc;
         }
     }
     // whatever the chain could not carry runs as one plain launch
@@ -1159,8 +1237,8 @@ int potrf_panel(hipStream_t st, const Ws& w, int J, int pe, Filler* fill = nullp
         rest.t0 = (int)fill->next;
         const long n = fill->total - fill->next;
         fill->next = fill->total;
-        hipLaunchKernelGGL((tile_gemm<T, OP_SYRK, TS, 4>), dim3((unsigned)(n * w.q)), dim3(256), 0, st, rest);
-        CHECK_LAUNCH("tile_gemm");
+        hipLaunchKernelGGL((syrk_rect_kernel<T>), dim3((unsigned)(n * w.q)), dim3(256), 0, st, rest);
+        CHECK_LAUNCH("syrk_rect_kernel");
     }
     return 0;
 }
@@ -1205,7 +1283,7 @@ int do_potrf(hipStream_t st, const Ws& w) {
             // columns, which the chain launches of panel J+1 carry as filler tiles (as many as those launches can
             // hide: g_fill_leaf / g_fill_small blocks each).
             Filler fill;
-            const int per_panel_blocks = ob * g_fill_leaf + (2 * ob - 1) * g_fill_small;
+            const int per_panel_blocks = ob * g_fill_leaf;
             for (int J = 0; J < w.nb; J += ob) {
                 const int pe = J + ob < w.nb ? J + ob : w.nb;
                 int rc = potrf_panel<T>(st, w, J, pe, fill.active() ? &fill : nullptr);
@@ -1215,7 +1293,7 @@ int do_potrf(hipStream_t st, const Ws& w) {
                 int cf = w.nb;                                         // first filler column
                 if (t128 && per_panel_blocks >= w.q && mid < w.nb) {
                     const long cap_tiles = per_panel_blocks / w.q;
-                    while (cf - 2 >= mid && trapezoid_tiles(w.nb, cf - 2, w.nb) <= cap_tiles) cf -= 2;
+                    while (cf - 2 >= mid && rect_tiles(w.nb, cf - 2, w.nb) <= cap_tiles) cf -= 2;
                 }
                 rc = potrf_trailing<T>(st, w, J, pe, pe, cf, t128);                    // one wide launch
                 if (rc) return rc;
@@ -1225,7 +1303,7 @@ int do_potrf(hipStream_t st, const Ws& w) {
                     f.A = w.base + w.off_M; f.B = f.A; f.C = (void*)f.A;
                     f.sA = f.sB = f.sC = w.mat; f.ldA = f.ldB = f.ldC = w.npad; f.nb = w.nb;
                     f.p0 = J; f.p1 = pe; f.p2 = cf; f.p3 = w.nb; f.q = w.q; f.t0 = 0;
-                    fill.total = trapezoid_tiles(w.nb, cf, w.nb);
+                    fill.total = rect_tiles(w.nb, cf, w.nb);
                 }
             }
             return 0;
