@@ -167,9 +167,7 @@ def main():
     if os.environ.get('LCGP_SMALL'):
         _hip.check(_hip.load().lcgp_set_tuning(6, int(os.environ['LCGP_SMALL'])), 'lcgp_set_tuning')
     if os.environ.get('LCGP_FILL'):
-        a, b = os.environ['LCGP_FILL'].split(',')
-        _hip.check(_hip.load().lcgp_set_tuning(11, int(a)), 'lcgp_set_tuning')
-        _hip.check(_hip.load().lcgp_set_tuning(12, int(b)), 'lcgp_set_tuning')
+        _hip.check(_hip.load().lcgp_set_tuning(11, int(os.environ['LCGP_FILL'].split(',')[0])), 'lcgp_set_tuning')
     if os.environ.get('LCGP_ANY'):
         _hip.check(_hip.load().lcgp_set_tuning(10, int(os.environ['LCGP_ANY'])), 'lcgp_set_tuning')
     if os.environ.get('LCGP_NW'):

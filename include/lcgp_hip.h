@@ -59,8 +59,8 @@ int lcgp_out_width(int d, int p);
  *          4200) / A^-1 = W^T W (7, default 1024) run on 64x64 tiles: with few components a launch is bounded by
  *          its longest tile (0 = always 128x128);
  *   key 8: the same switch for the trailing update of the Cholesky (default 768);
- *   key 11 / key 12: filler blocks (64x64 tiles of the previous panel's trailing update) carried by each diagonal-block
- *          launch (11, default 248; 128x64 tiles) ; key 12 is unused; 0 = no filler;
+ *   key 11: filler blocks (128x64 tiles of the previous panel's trailing update) carried by each diagonal-block launch
+ *          (default 248 = one per otherwise idle CU; 0 = no filler);
  *   key 3: 1 = look-ahead Cholesky (panel chain on an internal stream), 0 (default) = single stream;
  *   key 4: 1 = create that internal stream with the highest priority;
  *   key 1: number of component groups whose factorisation chains run on internal streams (default 1 = off, max 8). */

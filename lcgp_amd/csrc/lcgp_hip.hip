@@ -780,16 +780,9 @@ __global__ __launch_bounds__(256, 2) void syrk_rect_kernel(GemmArgs g) {
 // Heterogeneous launches.  The panel chain of the Cholesky (diagonal block -> panel TRMM -> panel update, 64 times)
 // is a sequence of small dependent launches that leave most CUs idle, and two HIP streams cannot overlap them with
 // the wide trailing update on this platform.  So the chain launches CARRY independent work: blocks
-// beyond the chain's own are "filler" tiles of the previous panel's trailing update (64x64 tiles, K = panel width),
+// beyond the chain's own are "filler" tiles of the previous panel's trailing update (128x64 tiles, K = panel width),
 // which touch columns the chain of the current panel neither reads nor writes.  No inter-workgroup dependency
 // exists inside such a launch; stream order between launches provides all the ordering.
-template <typename T, int OP>
-__global__ __launch_bounds__(256, 4) void tile_gemm_fill(GemmArgs g, GemmArgs f, int nprim) {
-    __shared__ __align__(16) unsigned char lds[4 * KT * (TS + 16) * sizeof(T)];
-    if ((int)blockIdx.x < nprim) gemm_body<T, OP, TS, 4>(g, blockIdx.x, lds);
-    else gemm_body<T, OP_SYRK, TS, 4>(f, blockIdx.x - nprim, lds);
-}
-
 template <typename T>
 __global__ __launch_bounds__(256) void leaf_fill_kernel(T* __restrict__ M, T* __restrict__ W, size_t mat, int npad, int jb,
                                                         double* __restrict__ logdet, int* __restrict__ info, int dbg,
@@ -1174,7 +1167,7 @@ int g_lookahead = 0;      // lcgp_set_tuning key 3: 1 = panel chain on its own s
         if (e__ != hipSuccess) return fail(what, e__);      \
     } while (0)
 
-// Filler work carried by the chain launches: a range of 64x64 tiles of a trailing update (see tile_gemm_fill).
+// Filler work carried by the diagonal-block launches: a range of 128x64 tiles of a trailing update (see leaf_fill_kernel).
 struct Filler {
     GemmArgs f;          // OP_SYRK on 64-tiles; f.q set
     long next = 0;       // next tile (trapezoid enumeration over columns [f.p2, f.p3))
@@ -1195,8 +1188,6 @@ struct Filler {
 int g_fill_leaf = 248;    // filler blocks (128x64 tiles) carried by a diagonal-block launch (lcgp_set_tuning key 11; 0 = off):
                           // one per otherwise idle CU is nearly free (launch 26 -> 30 us), a second one costs what it would
                           // cost in the wide launch
-int g_fill_small = 0;     // filler blocks carried by a panel TRMM / panel update launch (key 12; measured: they only
-                          // lengthen those 7-13 us launches)
 
 // one outer panel [J, pe): per 64-column step  diagonal block -> panel TRMM -> rank-64 update of the rest of the panel;
 // every launch may carry filler tiles
@@ -1281,7 +1272,7 @@ int do_potrf(hipStream_t st, const Ws& w) {
             // Two-level schedule with filler: the trailing update of panel J is split by columns into one wide
             // 128x128-tile launch (the columns of panel J+1 and as many more as do not fit below) and the right-most
             // columns, which the chain launches of panel J+1 carry as filler tiles (as many as those launches can
-            // hide: g_fill_leaf / g_fill_small blocks each).
+            // hide: g_fill_leaf blocks each).
             Filler fill;
             const int per_panel_blocks = ob * g_fill_leaf;
             for (int J = 0; J < w.nb; J += ob) {
@@ -1635,10 +1626,6 @@ int lcgp_set_tuning(int key, int value) {
     }
     if (key == 11) {
         g_fill_leaf = value;
-        return 0;
-    }
-    if (key == 12) {
-        g_fill_small = value;
         return 0;
     }
     if (key == 10) {
