@@ -166,6 +166,10 @@ def main():
         _hip.check(_hip.load().lcgp_set_tuning(0, int(os.environ['LCGP_OB'])), 'lcgp_set_tuning')
     if os.environ.get('LCGP_SMALL'):
         _hip.check(_hip.load().lcgp_set_tuning(6, int(os.environ['LCGP_SMALL'])), 'lcgp_set_tuning')
+    if os.environ.get('LCGP_STEP'):
+        _hip.check(_hip.load().lcgp_set_tuning(12, int(os.environ['LCGP_STEP'])), 'lcgp_set_tuning')
+    if os.environ.get('LCGP_FILL_STEP'):
+        _hip.check(_hip.load().lcgp_set_tuning(13, int(os.environ['LCGP_FILL_STEP'])), 'lcgp_set_tuning')
     if os.environ.get('LCGP_FILL'):
         _hip.check(_hip.load().lcgp_set_tuning(11, int(os.environ['LCGP_FILL'].split(',')[0])), 'lcgp_set_tuning')
     if os.environ.get('LCGP_ANY'):

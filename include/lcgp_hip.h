@@ -61,6 +61,11 @@ int lcgp_out_width(int d, int p);
  *   key 8: the same switch for the trailing update of the Cholesky (default 768);
  *   key 11: filler blocks (128x64 tiles of the previous panel's trailing update) carried by each diagonal-block launch
  *          (default 248 = one per otherwise idle CU; 0 = no filler);
+ *   key 12: 1 (default) = one launch per 64-column step of the Cholesky panel chain (panel TRMM with the previous
+ *          column's update folded in, the next diagonal block factored by the workgroup of the tile above it);
+ *          0 = diagonal block / panel TRMM / panel update as three dependent launches;
+ *   key 2: bit 2 (value 4) = barrier-per-pivot-pair variant of the diagonal-block kernel instead of the in-wave
+ *          16-column panels (bits 0 and 1 skip work for timing experiments and give wrong results);
  *   key 3: 1 = look-ahead Cholesky (panel chain on an internal stream), 0 (default) = single stream;
  *   key 4: 1 = create that internal stream with the highest priority;
  *   key 1: number of component groups whose factorisation chains run on internal streams (default 1 = off, max 8). */

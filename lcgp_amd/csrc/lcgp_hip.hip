@@ -304,26 +304,103 @@ __device__ __forceinline__ void leaf_pivot_group(double (&r)[16], double (*colbu
     }
 }
 
-constexpr int LEAF_LDS_BYTES = (2 * 2 * TS + TS + 2 * TS * (TS + 1)) * 8;   // colbuf + dinv + a + w = 69,120 B
+// ---- in-wave panel variant of the diagonal-block factorisation (default) ----
+// The 64x64 block is split into four 16-column panels, one per wave.  Wave w keeps block column w as fp64 MFMA
+// accumulators (lane (c = l & 15, g = l >> 4), reg e <-> row 16 rb + g + 4 e, column 16 w + c).  When its turn
+// comes it turns the panel into ROW layout through a private LDS scratch (lane = row, 16 registers = the panel's
+// columns) and factors it without leaving the wave: per pivot the pivot row is broadcast with v_readlane (SGPRs),
+// the update a_lc -= (u_l / d) u_pc is one FMA per remaining column and needs no barrier and no LDS; columns stay
+// un-scaled (u = l sqrt(d)) on the chain, the 1/sqrt(d) scaling runs beside it.  The finished panel goes to LDS as
+// lt[col][row]; after ONE barrier the waves to its right apply it to their accumulators with 16x16x4 MFMAs.
+// Chain per block: 64 x (readlane, rcp + 2 Newton steps, 2 FMAs) + 3 barriers instead of 32 barriers with an LDS
+// round trip each.
+__device__ __forceinline__ double readlane_f64(double v, int lane) {
+    union { double d; int i[2]; } u;
+    u.d = v;
+    u.i[0] = __builtin_amdgcn_readlane(u.i[0], lane);
+    u.i[1] = __builtin_amdgcn_readlane(u.i[1], lane);
+    return u.d;
+}
+
+__device__ __forceinline__ double fast_rsqrt(double a) {
+    double y = __builtin_amdgcn_rsq(a);
+    double e = fma(-(a * y), y, 1.0);
+    y = fma(0.5 * y, e, y);
+    e = fma(-(a * y), y, 1.0);
+    y = fma(0.5 * y, e, y);
+    return y;
+}
+
+constexpr int LEAF_LDT = TS + 1;
+constexpr int LEAF_SCR = 4 * TS * 17;                                     // per-wave [64][17] transposition scratch
+constexpr int LEAF_W_DOUBLES = LEAF_SCR > TS * LEAF_LDT ? LEAF_SCR : TS * LEAF_LDT;
+constexpr int LEAF_LDS_BYTES = (TS * LEAF_LDT + LEAF_W_DOUBLES + 2 * TS) * 8 + 16;   // lt + w/scratch + dinv + pivs + bad
 
 template <typename T>
-__device__ __forceinline__ void leaf_body(unsigned char* lds, int k, T* __restrict__ M, T* __restrict__ W, size_t mat,
-                                          int npad, int jb, double* __restrict__ logdet, int* __restrict__ info, int dbg) {
-    double (*colbuf)[2][TS] = (double (*)[2][TS])lds;
-    double* dinv = (double*)(lds + 2 * 2 * TS * 8);
-    double (*a)[TS + 1] = (double (*)[TS + 1])(lds + (2 * 2 * TS + TS) * 8);
-    double (*w)[TS + 1] = (double (*)[TS + 1])(lds + (2 * 2 * TS + TS + TS * (TS + 1)) * 8);
-    const int tid = threadIdx.x;
-    T* Mb = M + (size_t)k * mat + (size_t)jb * TS * npad + (size_t)jb * TS;
-    T* Wb = W + (size_t)k * mat + (size_t)jb * TS * npad + (size_t)jb * TS;
-    const int cj = tid & 63;
-    const int rg = tid >> 6;
-    double r[16];
+__device__ __forceinline__ void leaf_factor_panels(const T* __restrict__ Mb, int npad, double (*lt)[LEAF_LDT],
+                                                   double* scratch, double* dinv, double* pivs, int* bad, int jb) {
+    const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 15, lq = lane >> 4;
+    d4 acc[4];
 #pragma unroll
-    for (int m = 0; m < 16; ++m) {
-        const int i = rg + 4 * m;
-        r[m] = cj <= i ? (double)Mb[(size_t)i * npad + cj] : 0.0;
+    for (int rb = 0; rb < 4; ++rb)
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            acc[rb][e] = rb >= wv ? (double)Mb[(size_t)(rb * 16 + lq + 4 * e) * npad + wv * 16 + li] : 0.0;
+    double (*S)[17] = (double (*)[17])(scratch + wv * TS * 17);
+    int first_bad = 0;
+#pragma unroll 1
+    for (int kb = 0; kb < 4; ++kb) {
+        if (wv == kb) {
+#pragma unroll
+            for (int rb = 0; rb < 4; ++rb)
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (rb >= kb) S[rb * 16 + lq + 4 * e][li] = acc[rb][e];
+            double r[16];
+#pragma unroll
+            for (int c = 0; c < 16; ++c) r[c] = S[lane][c];
+            const int base = kb * 16;
+            double dmine = 1.0;                       // the pivot of row `lane` (lanes base .. base + 15)
+#pragma unroll
+            for (int s = 0; s < 16; ++s) {
+                const double u = r[s];
+                const double dp = readlane_f64(u, base + s);
+                dmine = lane == base + s ? u : dmine;
+                const double v = -u * fast_rcp(dp);
+#pragma unroll
+                for (int c = s + 1; c < 16; ++c) r[c] = fma(v, readlane_f64(u, base + c), r[c]);
+            }
+            const double rsl = fast_rsqrt(dmine);     // off the chain: l = u / sqrt(pivot)
+#pragma unroll
+            for (int s = 0; s < 16; ++s) r[s] *= readlane_f64(rsl, base + s);
+            if (lane >= base && lane < base + 16) { dinv[lane] = rsl; pivs[lane] = dmine; }
+            const unsigned long long bm = (__ballot(!(dmine > 0.0)) >> base) & 0xffffull;
+            if (bm) first_bad = jb * TS + base + __ffsll((long long)bm);
+#pragma unroll
+            for (int m = 0; m < 16; ++m) lt[kb * 16 + m][lane] = lane >= kb * 16 + m ? r[m] : 0.0;
+            if (lane == 0) bad[kb] = first_bad;
+        }
+        __syncthreads();
+        if (wv > kb) {
+#pragma unroll
+            for (int st = 0; st < 4; ++st) {
+                const double bv = lt[kb * 16 + 4 * st + lq][wv * 16 + li];
+#pragma unroll
+                for (int rb = 1; rb < 4; ++rb)
+                    if (rb >= wv)
+                        acc[rb] = __builtin_amdgcn_mfma_f64_16x16x4f64(-lt[kb * 16 + 4 * st + lq][rb * 16 + li], bv, acc[rb],
+                                                                       0, 0, 0);
+            }
+        }
     }
+}
+
+// barrier-per-pivot-pair variant (tuning key 2, bit 4): the block in registers of all 256 threads
+__device__ __forceinline__ void leaf_factor_pairs(const double* __restrict__ unused, double (&r)[16], double (*lt)[LEAF_LDT],
+                                                  double* scratch, double* dinv, double* pivs, int* bad, int jb, int dbg) {
+    double (*colbuf)[2][TS] = (double (*)[2][TS])scratch;
+    const int tid = threadIdx.x, cj = tid & 63, rg = tid >> 6;
     double piv = 1.0;
     int first_bad = 0;
     if (!(dbg & 1)) {
@@ -332,26 +409,56 @@ __device__ __forceinline__ void leaf_body(unsigned char* lds, int k, T* __restri
         leaf_pivot_group<8>(r, colbuf, 32, cj, rg, piv, first_bad, jb);
         leaf_pivot_group<12>(r, colbuf, 48, cj, rg, piv, first_bad, jb);
     }
-    // column cj is final up to the scaling by 1/sqrt(pivot)
-    const double rs = 1.0 / sqrt(piv);
+    const double rs = 1.0 / sqrt(piv);      // column cj is final up to the scaling by 1/sqrt(pivot)
 #pragma unroll
     for (int m = 0; m < 16; ++m) {
         const int i = rg + 4 * m;
-        const double l = i >= cj ? r[m] * rs : 0.0;
-        a[i][cj] = l;
-        w[i][cj] = 0.0;
-        Mb[(size_t)i * npad + cj] = (T)l;
+        lt[cj][i] = i >= cj ? r[m] * rs : 0.0;
     }
-    if (rg == 0) dinv[cj] = rs;
+    if (rg == 0) { dinv[cj] = rs; pivs[cj] = piv; }
+    if (tid < 4) bad[tid] = tid == 0 ? first_bad : 0;
+    __syncthreads();
+}
+
+template <typename T>
+__device__ __forceinline__ void leaf_body(unsigned char* lds, int k, T* __restrict__ M, T* __restrict__ W, size_t mat,
+                                          int npad, int jb, double* __restrict__ logdet, int* __restrict__ info, int dbg) {
+    double (*lt)[LEAF_LDT] = (double (*)[LEAF_LDT])lds;                   // lt[col][row] = L[row][col]
+    double* scratch = (double*)lds + TS * LEAF_LDT;
+    double (*w)[LEAF_LDT] = (double (*)[LEAF_LDT])scratch;                // the inverse; overlays the factor's scratch
+    double* dinv = scratch + LEAF_W_DOUBLES;
+    double* pivs = dinv + TS;
+    int* bad = (int*)(pivs + TS);
+    const int tid = threadIdx.x;
+    T* Mb = M + (size_t)k * mat + (size_t)jb * TS * npad + (size_t)jb * TS;
+    T* Wb = W + (size_t)k * mat + (size_t)jb * TS * npad + (size_t)jb * TS;
+    const int cj = tid & 63;
+    const int rg = tid >> 6;
+    if (dbg & 4) {
+        double r[16];
+#pragma unroll
+        for (int m = 0; m < 16; ++m) {
+            const int i = rg + 4 * m;
+            r[m] = cj <= i ? (double)Mb[(size_t)i * npad + cj] : 0.0;
+        }
+        leaf_factor_pairs(nullptr, r, lt, scratch, dinv, pivs, bad, jb, dbg);
+    } else {
+        leaf_factor_panels<T>(Mb, npad, lt, scratch, dinv, pivs, bad, jb);
+    }
+#pragma unroll
+    for (int m = 0; m < 16; ++m) {
+        const int i = rg + 4 * m;
+        Mb[(size_t)i * npad + cj] = (T)lt[cj][i];
+    }
     if (tid < TS) {   // wave 0: 1/2 sum log(pivot)
-        double lg = 0.5 * log(piv);
+        double lg = 0.5 * log(pivs[tid]);
         for (int off = 32; off > 0; off >>= 1) lg += __shfl_xor(lg, off);
         if (tid == 0) {
             logdet[k] += lg;
-            if (first_bad && info[k] == 0) info[k] = first_bad;
+            const int fb = bad[0] ? bad[0] : bad[1] ? bad[1] : bad[2] ? bad[2] : bad[3];
+            if (fb && info[k] == 0) info[k] = fb;
         }
     }
-    __syncthreads();
     if (dbg & 2) return;
     // ---- inverse of the 64x64 lower-triangular block, blocked by 16 ----
     // (a) the four 16x16 diagonal blocks: thread = one column, kept in registers (solve L w = e_cl)
@@ -363,7 +470,7 @@ __device__ __forceinline__ void leaf_body(unsigned char* lds, int k, T* __restri
         for (int i = 0; i < 16; ++i) {
             double sacc = i == cl ? -1.0 : 0.0;
 #pragma unroll
-            for (int m = 0; m < i; ++m) sacc = fma(a[b0 + i][b0 + m], wc[m], sacc);
+            for (int m = 0; m < i; ++m) sacc = fma(lt[b0 + m][b0 + i], wc[m], sacc);
             wc[i] = -sacc * dinv[b0 + i];
         }
 #pragma unroll
@@ -383,7 +490,7 @@ __device__ __forceinline__ void leaf_body(unsigned char* lds, int k, T* __restri
                 for (int mb = bb; mb < ab; ++mb) {
 #pragma unroll
                     for (int st = 0; st < 4; ++st)
-                        tacc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[ab * 16 + li][mb * 16 + 4 * st + lq],
+                        tacc = __builtin_amdgcn_mfma_f64_16x16x4f64(lt[mb * 16 + 4 * st + lq][ab * 16 + li],
                                                                     w[mb * 16 + 4 * st + lq][bb * 16 + li], tacc, 0, 0, 0);
                 }
                 d4 wacc = {0.0, 0.0, 0.0, 0.0};
@@ -793,6 +900,168 @@ __global__ __launch_bounds__(256) void leaf_fill_kernel(T* __restrict__ M, T* __
 }
 
 // ---------------------------------------------------------------------------------------------------
+// One launch per 64-column step of the panel chain (lcgp_set_tuning key 12, default on).
+// The three dependent launches of a step (diagonal block -> panel TRMM -> rank-64 update of the rest of the panel)
+// are re-cut so that a step needs ONE launch X_c with no dependency between its workgroups:
+//   * TRMM tiles (r, c), r > c:   L[r,c] = (A[r,c] - L[r,c-1] L[c,c-1]^T) W_cc^T   -- the contribution of the
+//     PREVIOUS column is applied by the tile itself, the older ones arrived through the delayed updates below;
+//     a tile whose row lies inside the panel also applies  A[r,r] -= L[r,c] L[r,c]^T  to its row's diagonal tile
+//     (so the panel's diagonal tiles have exactly one writer per launch);
+//   * the tile (c+1, c) is "special": after the two steps above its workgroup factors and inverts the diagonal
+//     block c+1 (leaf_body), which is what launch X_{c+1} needs;
+//   * delayed updates: column c-1 applied to the tiles (r, c'), c < c' < panel end, r > c'  (strictly below the
+//     diagonal; column c-1 became final in X_{c-1});
+//   * filler tiles of the previous panel's trailing update (syrk_rect_body) as before.
+// Per panel of 4 columns: 1 diagonal-block launch + 4 step launches instead of 12 launches, and the chain of a step
+// is  2-3 K=64 products + one diagonal block  on a single workgroup.
+// ---------------------------------------------------------------------------------------------------
+struct StepArgs {
+    void* M; void* W; size_t mat; int npad; int nb;
+    int c, J, pe;        // this step's column, the panel [J, pe)  (64-block units)
+    int q;
+    int has_special;     // tile (c+1, c) continues with the diagonal block c+1  (c + 1 < pe)
+    int n_trmm;          // TRMM tiles per component INCLUDING the special one: rows c+1 .. nb-1
+    int n_upd;           // delayed-update tiles per component
+    double* logdet; int* info; int dbg;
+    int nfill;           // filler blocks
+    GemmArgs f;          // filler
+};
+
+template <typename T>
+struct Tile64 {          // 64x64 tile on 256 threads: wave (wm, wn) owns a 32x32 quadrant = 2x2 MFMA accumulators
+    typedef typename Mfma<T>::acc_t acc_t;
+    static constexpr int LD = TS + 16, NT = 256, EPT = TS * KT / NT, SPT = TS / KT;
+    static __device__ __forceinline__ void load(acc_t (&acc)[2][2], const T* Ct, int ld, int lane, int wm0, int wn0) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    acc[i][j][e] = Ct[(size_t)(wm0 + i * 16 + Mfma<T>::row(lane, e)) * ld + wn0 + j * 16 + (lane & 15)];
+    }
+    static __device__ __forceinline__ void zero(acc_t (&acc)[2][2]) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[i][j][e] = 0;
+    }
+    static __device__ __forceinline__ void store(const acc_t (&acc)[2][2], T* Ct, int ld, int lane, int wm0, int wn0) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    Ct[(size_t)(wm0 + i * 16 + Mfma<T>::row(lane, e)) * ld + wn0 + j * 16 + (lane & 15)] = acc[i][j][e];
+    }
+    // acc += (NEG ? -1 : 1) * A B^T,  A and B 64x64 tiles (element (m, k) at P[m * ld + k]); all four K stages are
+    // fetched up front (one memory latency), then staged through the two LDS buffers
+    template <bool NEG>
+    static __device__ __forceinline__ void mma(acc_t (&acc)[2][2], const T* A0, int ldA, const T* B0, int ldB, T* lds,
+                                               int tid, int lane, int wm0, int wn0) {
+        T* As = lds;
+        T* Bs = As + 2 * KT * LD;
+        T pa[SPT][EPT], pb[SPT][EPT];
+#pragma unroll
+        for (int s = 0; s < SPT; ++s) {
+            load_stage<T, MK, TS, NT>(A0, ldA, s * KT, pa[s], tid);
+            load_stage<T, MK, TS, NT>(B0, ldB, s * KT, pb[s], tid);
+        }
+#pragma unroll
+        for (int s = 0; s < SPT; ++s) {
+            store_stage<T, MK, TS, NT>(As + (s & 1) * KT * LD, pa[s], tid);
+            store_stage<T, MK, TS, NT>(Bs + (s & 1) * KT * LD, pb[s], tid);
+            __syncthreads();
+            const T* as = As + (s & 1) * KT * LD;
+            const T* bs = Bs + (s & 1) * KT * LD;
+#pragma unroll
+            for (int kk = 0; kk < KT / 4; ++kk) {
+                const int krow = (kk * 4 + (lane >> 4)) * LD;
+                T af[2], bf[2];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const T v = as[krow + wm0 + i * 16 + (lane & 15)];
+                    af[i] = NEG ? -v : v;
+                }
+#pragma unroll
+                for (int j = 0; j < 2; ++j) bf[j] = bs[krow + wn0 + j * 16 + (lane & 15)];
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) acc[i][j] = Mfma<T>::run(af[i], bf[j], acc[i][j]);
+            }
+        }
+    }
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void chain_step_kernel(StepArgs a) {
+    __shared__ __align__(16) unsigned char lds[LEAF_LDS_BYTES];
+    typedef Tile64<T> TL;
+    int b = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm0 = (wave >> 1) * 32, wn0 = (wave & 1) * 32;
+    const int ld = a.npad;
+    // block order = longest first: the special tiles (chain of the step), the filler tiles, then the short ones
+    const int nspecial = a.has_special * a.q;
+    int t = -1, k = 0;
+    if (b < nspecial) { t = 0; k = b; }
+    else if (b < nspecial + a.nfill) { syrk_rect_body<T>(a.f, b - nspecial, lds); return; }
+    else {
+        b -= nspecial + a.nfill;
+        if (b < (a.n_trmm - a.has_special) * a.q) { k = b % a.q; t = b / a.q + a.has_special; }
+        else b -= (a.n_trmm - a.has_special) * a.q;
+    }
+    if (t >= 0) {
+        if (t == 0 && a.has_special) __builtin_amdgcn_s_setprio(3);   // the chain of the step shares its CU with other tiles
+        const int c = a.c, r = c + 1 + t;
+        T* Mk = (T*)a.M + (size_t)k * a.mat;
+        const T* Wk = (const T*)a.W + (size_t)k * a.mat;
+        T* Ct = Mk + (size_t)r * TS * ld + (size_t)c * TS;
+        typename TL::acc_t acc[2][2];
+        if (c > a.J) {       // the previous column's contribution to this tile
+            TL::load(acc, Ct, ld, lane, wm0, wn0);
+            TL::template mma<true>(acc, Mk + (size_t)r * TS * ld + (size_t)(c - 1) * TS, ld,
+                                   Mk + (size_t)c * TS * ld + (size_t)(c - 1) * TS, ld, (T*)lds, tid, lane, wm0, wn0);
+            TL::store(acc, Ct, ld, lane, wm0, wn0);
+            __syncthreads();
+        }
+        TL::zero(acc);
+        TL::template mma<false>(acc, Ct, ld, Wk + (size_t)c * TS * ld + (size_t)c * TS, ld, (T*)lds, tid, lane, wm0, wn0);
+        TL::store(acc, Ct, ld, lane, wm0, wn0);         // L[r, c]  (every load of the old tile preceded the mma's barriers)
+        if (r < a.pe) {
+            __syncthreads();
+            T* Dt = Mk + (size_t)r * TS * ld + (size_t)r * TS;
+            TL::load(acc, Dt, ld, lane, wm0, wn0);
+            TL::template mma<true>(acc, Ct, ld, Ct, ld, (T*)lds, tid, lane, wm0, wn0);
+            TL::store(acc, Dt, ld, lane, wm0, wn0);
+            if (a.has_special && t == 0) {
+                __syncthreads();
+                leaf_body<T>(lds, k, (T*)a.M, (T*)a.W, a.mat, a.npad, c + 1, a.logdet, a.info, a.dbg);
+            }
+        }
+        return;
+    }
+    {
+        k = b % a.q;
+        t = b / a.q;
+        int cc = a.c + 1;
+        while (t >= a.nb - cc - 1) { t -= a.nb - cc - 1; ++cc; }
+        const int r = cc + 1 + t, j = a.c - 1;
+        T* Mk = (T*)a.M + (size_t)k * a.mat;
+        T* Ct = Mk + (size_t)r * TS * ld + (size_t)cc * TS;
+        typename TL::acc_t acc[2][2];
+        TL::load(acc, Ct, ld, lane, wm0, wn0);
+        TL::template mma<true>(acc, Mk + (size_t)r * TS * ld + (size_t)j * TS, ld,
+                               Mk + (size_t)cc * TS * ld + (size_t)j * TS, ld, (T*)lds, tid, lane, wm0, wn0);
+        TL::store(acc, Ct, ld, lane, wm0, wn0);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
 // b_k[i] = sum_a Y[a, i] psi_k[a]   (lcgp.py:646 + 657-658 collapsed; lcgp.py:608-610 for rep)
 // ---------------------------------------------------------------------------------------------------
 template <typename T>
@@ -1137,7 +1406,8 @@ int pool_get(StreamPool*& out) {
 int g_outer_blocks = 4;   // width of the outer Cholesky panel in 64-blocks (lcgp_set_tuning key 0)
 int g_super_blocks = 0;   // width of the Cholesky super-panel in 64-blocks (lcgp_set_tuning key 5); 0 = same as the panel
                           // (measured: 8, 16, 32 are not faster at n=4096)
-int g_debug_mask = 0;     // timing experiments only (lcgp_set_tuning key 2): 1 = skip pivots, 2 = skip inverse
+int g_debug_mask = 0;     // lcgp_set_tuning key 2: 1 = skip pivots, 2 = skip inverse (timing experiments only, wrong results);
+                          // 4 = barrier-per-pivot-pair diagonal-block variant instead of the in-wave panels
 
 // 128 x 64 filler tiles over the 64-columns [c_lo, c_hi): column c has nb/2 - c/2 row blocks
 inline long rect_tiles(int nb, int c_lo, int c_hi) {
@@ -1185,6 +1455,9 @@ struct Filler {
     }
 };
 
+int g_step_fused = 1;    // lcgp_set_tuning key 12: 1 = one launch per 64-column step of the panel chain (chain_step_kernel),
+                          // 0 = diagonal block / panel TRMM / panel update as three launches
+int g_fill_step = 248;    // filler blocks carried by a chain_step_kernel launch (lcgp_set_tuning key 13)
 int g_fill_leaf = 248;    // filler blocks (128x64 tiles) carried by a diagonal-block launch (lcgp_set_tuning key 11; 0 = off):
                           // one per otherwise idle CU is nearly free (launch 26 -> 30 us), a second one costs what it would
                           // cost in the wide launch
@@ -1199,6 +1472,34 @@ int potrf_panel(hipStream_t st, const Ws& w, int J, int pe, Filler* fill = nullp
     int* info = (int*)(w.base + w.off_info);
     GemmArgs g, fa;
     g.sA = g.sB = g.sC = w.mat; g.ldA = g.ldB = g.ldC = w.npad; g.nb = w.nb; g.q = w.q; g.t0 = 0;
+    if (g_step_fused) {
+        // diagonal block J on its own, then ONE launch per column (chain_step_kernel)
+        int nf = fill ? fill->take(g_fill_leaf, fa) : 0;
+        if (nf > 0) {
+            hipLaunchKernelGGL((leaf_fill_kernel<T>), dim3(w.q + nf), dim3(256), 0, st, M, W, w.mat, w.npad, J, logdet, info,
+                               g_debug_mask, w.q, fa);
+        } else {
+            hipLaunchKernelGGL((leaf_kernel<T>), dim3(w.q), dim3(256), 0, st, M, W, w.mat, w.npad, J, logdet, info,
+                               g_debug_mask);
+        }
+        CHECK_LAUNCH("leaf_kernel");
+        for (int c = J; c < pe && c + 1 < w.nb; ++c) {
+            StepArgs a;
+            a.M = M; a.W = W; a.mat = w.mat; a.npad = w.npad; a.nb = w.nb;
+            a.c = c; a.J = J; a.pe = pe; a.q = w.q;
+            a.has_special = c + 1 < pe ? 1 : 0;
+            a.n_trmm = w.nb - 1 - c;
+            a.n_upd = 0;
+            if (c > J)
+                for (int cc = c + 1; cc < pe; ++cc) a.n_upd += w.nb - cc - 1;
+            a.logdet = logdet; a.info = info; a.dbg = g_debug_mask;
+            nf = (fill && a.has_special) ? fill->take(g_fill_step, fa) : 0;
+            a.f = fa; a.nfill = nf;
+            const long nblk = (long)(a.n_trmm + a.n_upd) * w.q + nf;
+            hipLaunchKernelGGL((chain_step_kernel<T>), dim3((unsigned)nblk), dim3(256), 0, st, a);
+            CHECK_LAUNCH("chain_step_kernel");
+        }
+    } else
     for (int c = J; c < pe; ++c) {
         int nf = fill ? fill->take(g_fill_leaf, fa) : 0;
         if (nf > 0) {
@@ -1274,7 +1575,7 @@ int do_potrf(hipStream_t st, const Ws& w) {
             // columns, which the chain launches of panel J+1 carry as filler tiles (as many as those launches can
             // hide: g_fill_leaf blocks each).
             Filler fill;
-            const int per_panel_blocks = ob * g_fill_leaf;
+            const int per_panel_blocks = g_step_fused ? g_fill_leaf + (ob - 1) * g_fill_step : ob * g_fill_leaf;
             for (int J = 0; J < w.nb; J += ob) {
                 const int pe = J + ob < w.nb ? J + ob : w.nb;
                 int rc = potrf_panel<T>(st, w, J, pe, fill.active() ? &fill : nullptr);
@@ -1626,6 +1927,14 @@ int lcgp_set_tuning(int key, int value) {
     }
     if (key == 11) {
         g_fill_leaf = value;
+        return 0;
+    }
+    if (key == 12) {
+        g_step_fused = value ? 1 : 0;
+        return 0;
+    }
+    if (key == 13) {
+        g_fill_step = value;
         return 0;
     }
     if (key == 10) {
