@@ -5,6 +5,7 @@ import ctypes as C
 
 import numpy as np
 import pytest
+import torch
 
 from lcgp_amd import LCGP, synth, _hip
 from oracle import lcgp_oracle as orc
@@ -132,18 +133,90 @@ def test_c_abi_argument_checks():
     assert lib.lcgp_set_tuning(0, 4) == 0
 
 
+def _reset_tuning(lib):
+    for key, val in ((0, 4), (5, 0), (1, 1), (3, 0), (2, 0), (12, 1), (11, 248), (13, 248)):
+        lib.lcgp_set_tuning(key, val)
+
+
 def test_tuning_knobs_do_not_change_results():
+    """Every schedule / kernel variant selectable through lcgp_set_tuning computes the same numbers:
+    panel widths, super-panels, stream groups, look-ahead, three-launch chain steps (key 12 = 0), the
+    barrier-per-pivot-pair diagonal block (key 2 bit 2), no filler / different filler sizes."""
     x, y = synth.make_full(326, 700, 3, 4, 4)
     m = LCGP(y=y, x=x, q=4)
     u = synth.param_points(326, m._get_flat())[1]
     ref_v, ref_g = m.loss_and_grad(u)
     lib = _hip.load()
     try:
-        for key, val in ((0, 2), (0, 8), (5, 8), (1, 2), (3, 1)):
-            assert lib.lcgp_set_tuning(key, val) == 0
+        for settings in (((0, 2),), ((0, 8),), ((5, 8),), ((1, 2),), ((3, 1),), ((12, 0),), ((2, 4),),
+                         ((12, 0), (2, 4)), ((11, 0), (13, 0)), ((11, 16), (13, 24)), ((0, 3),), ((0, 3), (12, 0))):
+            for key, val in settings:
+                assert lib.lcgp_set_tuning(key, val) == 0
             v, g = m.loss_and_grad(u)
-            assert abs(v - ref_v) <= 1e-11 * abs(ref_v)
-            assert np.max(np.abs(g - ref_g)) <= 1e-10 * np.max(np.abs(ref_g))
-            lib.lcgp_set_tuning(0, 4); lib.lcgp_set_tuning(5, 0); lib.lcgp_set_tuning(1, 1); lib.lcgp_set_tuning(3, 0)
+            assert abs(v - ref_v) <= 1e-11 * abs(ref_v), settings
+            assert np.max(np.abs(g - ref_g)) <= 1e-10 * np.max(np.abs(ref_g)), settings
+            _reset_tuning(lib)
     finally:
-        lib.lcgp_set_tuning(0, 4); lib.lcgp_set_tuning(5, 0); lib.lcgp_set_tuning(1, 1); lib.lcgp_set_tuning(3, 0)
+        _reset_tuning(lib)
+
+
+def test_chain_variants_match_oracle_at_several_sizes():
+    """The fused chain step and the in-wave diagonal block against the oracle where the panel structure differs:
+    a single block, a partial panel, several panels with a ragged last one."""
+    lib = _hip.load()
+    try:
+        for seed, n in ((331, 64), (332, 200), (333, 330), (334, 900)):
+            x, y = synth.make_full(seed, n, 2, 6, 2)
+            o = orc.OracleLCGP(y=y, x=x, q=2)
+            u = synth.param_points(seed, o.get_unconstrained())[1]
+            for settings in ((), ((12, 0),), ((2, 4),)):
+                for key, val in settings:
+                    assert lib.lcgp_set_tuning(key, val) == 0
+                m = LCGP(y=y, x=x, q=2)
+                _same(m, o, u)
+                _reset_tuning(lib)
+    finally:
+        _reset_tuning(lib)
+
+
+def _first_bad_pivot(a):
+    """1-based index of the first non-positive pivot of an unblocked Cholesky of `a` (LAPACK's info), 0 if none."""
+    a = a.copy()
+    n = a.shape[0]
+    for j in range(n):
+        if not a[j, j] > 0.0:
+            return j + 1
+        a[j + 1:, j] /= a[j, j]
+        a[j + 1:, j + 1:] -= np.outer(a[j + 1:, j], a[j + 1:, j]) * a[j, j]
+    return 0
+
+
+@pytest.mark.parametrize('variant', [(), ((2, 4),), ((12, 0),)])
+def test_info_is_the_first_bad_pivot(variant):
+    """info of the output block = position of the first non-positive pivot (as LAPACK dpotrf reports it), wherever
+    it falls: first block, inside a later 16-column panel of a diagonal block, in a later block or panel."""
+    lib = _hip.load()
+    x, y = synth.make_full(340, 330, 2, 4, 3)
+    m = LCGP(y=y, x=x, q=3)
+    ell, scale, nug = m.lLmb.numpy(), m.lLmb0.numpy(), m.lnugGPs.numpy()
+    xs = m.x.numpy()
+    want, dvals = [], []
+    for k, target in enumerate((1, 40, 300)):
+        c = orc.matern32(xs, xs, ell[k], scale[k], nug[k])
+        # A = I + D C is indefinite for D < -1 / lambda_max(C); pick D so that the leading `target`-minor fails first
+        w = np.linalg.eigvalsh(c[:target, :target])
+        dk = -1.0 / w[-1] * 1.05
+        a = np.eye(330) + dk * c
+        want.append(_first_bad_pivot(a))
+        dvals.append(dk)
+    assert want[0] >= 1 and len(set(want)) > 1
+    m.diag_D = torch.as_tensor(np.array(dvals))
+    eng = m._get_engine()
+    sig_eff = np.exp(0.5 * np.repeat(m.lsigma2s.numpy(), np.asarray(m.diag_error_structure, int))) / m._std
+    try:
+        for key, val in variant:
+            assert lib.lcgp_set_tuning(key, val) == 0
+        out = eng.evaluate(m._theta_rows(sig_eff))
+    finally:
+        _reset_tuning(lib)
+    assert [int(r[2]) for r in out] == want
