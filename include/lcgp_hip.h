@@ -58,7 +58,7 @@ int lcgp_out_width(int d, int p);
  *   key 6 / key 7: below this many 128x128 tiles per launch (components x tiles) the triangular inverse (6, default
  *          4200) / A^-1 = W^T W (7, default 1024) run on 64x64 tiles: with few components a launch is bounded by
  *          its longest tile (0 = always 128x128);
- *   key 8: the same switch for the trailing update of the Cholesky (default 768);
+ *   key 8: the same switch for the trailing update of the Cholesky (default 2000);
  *   key 11: filler blocks (128x64 tiles of the previous panel's trailing update) carried by each diagonal-block launch
  *          (default 248 = one per otherwise idle CU; 0 = no filler);
  *   key 12: 1 (default) = one launch per 64-column step of the Cholesky panel chain (panel TRMM with the previous

@@ -1424,7 +1424,7 @@ inline int trapezoid_tiles(int nb, int c_lo, int c_hi) {
 // step is  diagonal block -> panel TRMM -> rank-64 update of the REST OF THE PANEL only;  the trailing matrix
 // is touched once per outer panel with K = 64 * g_outer_blocks (read-modify-write traffic / g_outer_blocks).
 int g_chain_prio = 0;     // lcgp_set_tuning key 4: 1 = create the chain stream with the highest priority (before first use)
-int g_small_tiles_syrk = 768;   // lcgp_set_tuning key 8
+int g_small_tiles_syrk = 2000;  // lcgp_set_tuning key 8
 int g_any_order = 0;      // lcgp_set_tuning key 10: launch the first diagonal block of a panel without the barrier bit
 int g_lookahead = 0;      // lcgp_set_tuning key 3: 1 = panel chain on its own stream ahead of the trailing update.
                           // OFF by default: measured on MI355X / ROCm 7.2, as soon as one HIP stream waits on another

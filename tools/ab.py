@@ -1,0 +1,69 @@
+"""A/B timing of tuning settings inside ONE process on ONE box (box-to-box noise is +-3 %).
+
+usage: python tools/ab.py [--q Q] [--n N] [--reps R] [--steps K] "name:key=val,key=val" "name2:..." ...
+Each setting is a comma-separated list of lcgp_set_tuning key=value pairs (empty = defaults).  The settings are
+timed round-robin R times, K evaluations each; prints the min and mean ms per evaluation and the potrf stage time.
+"""
+import argparse
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, '.')
+from lcgp_amd import LCGP, synth, _hip  # noqa: E402
+
+DEFAULTS = {0: 4, 1: 1, 2: 0, 3: 0, 5: 0, 6: 4200, 7: 1024, 8: 2000, 9: 8, 10: 0, 11: 248, 12: 1, 13: 248}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--q', type=int, default=8)
+    ap.add_argument('--n', type=int, default=4096)
+    ap.add_argument('--reps', type=int, default=4)
+    ap.add_argument('--steps', type=int, default=6)
+    ap.add_argument('settings', nargs='+')
+    a = ap.parse_args()
+    x, y, cfg = synth.make_config(3)
+    x, y = x[:a.n], y[:, :a.n]
+    m = LCGP(y=y, x=x, q=a.q)          # q components = one rank's share of the headline configuration
+    lib = _hip.load()
+    u = m._get_flat()
+    eng = None
+    res = {}
+    names = []
+    for s in a.settings:
+        name, _, kv = s.partition(':')
+        pairs = [tuple(int(t) for t in p.split('=')) for p in kv.split(',') if p]
+        names.append((name, pairs))
+        res[name] = []
+
+    def apply(pairs):
+        for k, v in DEFAULTS.items():
+            lib.lcgp_set_tuning(k, v)
+        for k, v in pairs:
+            assert lib.lcgp_set_tuning(k, v) == 0, (k, v)
+
+    eng = m._get_engine()
+    sig_eff = np.exp(0.5 * np.repeat(m.lsigma2s.numpy(), np.asarray(m.diag_error_structure, int))) / m._std
+    theta = m._theta_rows(sig_eff)
+    eng.evaluate(theta)
+    for r in range(a.reps):
+        for name, pairs in names:
+            apply(pairs)
+            eng.evaluate(theta)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(a.steps):
+                eng.enqueue()
+            torch.cuda.synchronize()
+            res[name].append((time.perf_counter() - t0) / a.steps * 1e3)
+    apply(())
+    for name, _ in names:
+        v = np.array(res[name])
+        print(f"{name:28s} min {v.min():8.3f} ms   mean {v.mean():8.3f} ms   ({a.reps} x {a.steps} evaluations, q_local={a.q}, n={a.n})")
+
+
+if __name__ == '__main__':
+    main()
