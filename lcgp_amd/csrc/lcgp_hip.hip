@@ -538,6 +538,8 @@ struct GemmArgs {
     int p0, p1, p2, p3;                         // op specific
     int q;                                      // components in this launch
     int t0;                                     // first tile of this launch (OP_SYRK: a launch may cover a sub-range)
+    int skipq;                                  // OP_SYRK on 128-tiles: tile 0 leaves its top-left 64x64 quadrant alone
+                                                // (the diagonal block there is factored by the same launch, wide_leaf_kernel)
 };
 
 // one K-stage (KT = 16 k values) of a TM-row operand tile: global -> registers -> LDS [k][m], ld = TM + 16;
@@ -785,6 +787,9 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, const int lin /*blo
                 const int row = wm0 + mi * 16 + Mfma<T>::row(lane, e);
                 const int col = wn0 + ni * 16 + (lane & 15);
                 T* dst = Ct + (size_t)row * g.ldC + col;
+                if constexpr (OP == OP_SYRK && TM == 128) {
+                    if (g.skipq && bid + g.t0 == 0 && row < TS && col < TS) continue;
+                }
                 if constexpr (PRELOAD_C) {
                     *dst = acc[mi][ni][e];
                 } else {
@@ -1059,6 +1064,39 @@ __global__ __launch_bounds__(256) void chain_step_kernel(StepArgs a) {
                                Mk + (size_t)cc * TS * ld + (size_t)j * TS, ld, (T*)lds, tid, lane, wm0, wn0);
         TL::store(acc, Ct, ld, lane, wm0, wn0);
     }
+}
+
+// Trailing update of a panel that also factors the FIRST diagonal block of the next panel: the first q workgroups
+// apply the panel to that 64x64 block themselves (K = panel width) and continue with leaf_body, the others are the
+// tiles of the wide update (tile 0 of the 128-tile form leaves that quadrant alone; the 64-tile form starts at tile 1).
+// The next panel's chain then starts with its first step launch -- one dependent launch less per panel, and the
+// diagonal block hides under the update.
+template <typename T, int TM>
+__global__ __launch_bounds__(256, 2) void wide_leaf_kernel(GemmArgs g, T* __restrict__ M, T* __restrict__ W, size_t mat,
+                                                           int npad, int jb, int J, double* __restrict__ logdet,
+                                                           int* __restrict__ info, int dbg) {
+    constexpr int WIDE_LDS = 4 * KT * (TM + 16) * (int)sizeof(T);
+    __shared__ __align__(16) unsigned char lds[WIDE_LDS > LEAF_LDS_BYTES ? WIDE_LDS : LEAF_LDS_BYTES];
+    const int q = g.q;
+    if ((int)blockIdx.x < q) {
+        typedef Tile64<T> TL;
+        const int k = blockIdx.x;
+        const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+        const int wm0 = (wave >> 1) * 32, wn0 = (wave & 1) * 32;
+        T* Mk = M + (size_t)k * mat;
+        T* Dt = Mk + (size_t)jb * TS * npad + (size_t)jb * TS;
+        typename TL::acc_t acc[2][2];
+        TL::load(acc, Dt, npad, lane, wm0, wn0);
+        for (int j = J; j < jb; ++j) {
+            const T* Lt = Mk + (size_t)jb * TS * npad + (size_t)j * TS;
+            TL::template mma<true>(acc, Lt, npad, Lt, npad, (T*)lds, tid, lane, wm0, wn0);
+        }
+        TL::store(acc, Dt, npad, lane, wm0, wn0);
+        __syncthreads();
+        leaf_body<T>(lds, k, M, W, mat, npad, jb, logdet, info, dbg);
+        return;
+    }
+    gemm_body<T, OP_SYRK, TM, 4>(g, blockIdx.x - q, lds);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -1342,6 +1380,7 @@ int launch_gemm(hipStream_t st, const GemmArgs& g, int ntiles, int q) {
     GemmArgs h = g;
     h.q = q;
     h.t0 = 0;
+    h.skipq = 0;
     if (TM == 128 && g_waves128 == 4) {
         hipLaunchKernelGGL((tile_gemm<T, OP, TM, 4>), dim3((unsigned)ntiles * q), dim3(256), 0, st, h);
         CHECK_LAUNCH("tile_gemm");
@@ -1457,6 +1496,8 @@ struct Filler {
 
 int g_step_fused = 1;    // lcgp_set_tuning key 12: 1 = one launch per 64-column step of the panel chain (chain_step_kernel),
                           // 0 = diagonal block / panel TRMM / panel update as three launches
+int g_leaf_in_wide = 1024;// lcgp_set_tuning key 14: a trailing-update launch of at most this many 64x64 tiles also factors the next
+                          // panel's first diagonal block (0 = never)
 int g_fill_step = 248;    // filler blocks carried by a chain_step_kernel launch (lcgp_set_tuning key 13)
 int g_fill_leaf = 248;    // filler blocks (128x64 tiles) carried by a diagonal-block launch (lcgp_set_tuning key 11; 0 = off):
                           // one per otherwise idle CU is nearly free (launch 26 -> 30 us), a second one costs what it would
@@ -1465,7 +1506,7 @@ int g_fill_leaf = 248;    // filler blocks (128x64 tiles) carried by a diagonal-
 // one outer panel [J, pe): per 64-column step  diagonal block -> panel TRMM -> rank-64 update of the rest of the panel;
 // every launch may carry filler tiles
 template <typename T>
-int potrf_panel(hipStream_t st, const Ws& w, int J, int pe, Filler* fill = nullptr) {
+int potrf_panel(hipStream_t st, const Ws& w, int J, int pe, Filler* fill = nullptr, bool leaf_done = false) {
     T* M = (T*)(w.base + w.off_M);
     T* W = (T*)(w.base + w.off_W);
     double* logdet = (double*)(w.base + w.off_logdet);
@@ -1474,15 +1515,18 @@ int potrf_panel(hipStream_t st, const Ws& w, int J, int pe, Filler* fill = nullp
     g.sA = g.sB = g.sC = w.mat; g.ldA = g.ldB = g.ldC = w.npad; g.nb = w.nb; g.q = w.q; g.t0 = 0;
     if (g_step_fused) {
         // diagonal block J on its own, then ONE launch per column (chain_step_kernel)
-        int nf = fill ? fill->take(g_fill_leaf, fa) : 0;
-        if (nf > 0) {
-            hipLaunchKernelGGL((leaf_fill_kernel<T>), dim3(w.q + nf), dim3(256), 0, st, M, W, w.mat, w.npad, J, logdet, info,
-                               g_debug_mask, w.q, fa);
-        } else {
-            hipLaunchKernelGGL((leaf_kernel<T>), dim3(w.q), dim3(256), 0, st, M, W, w.mat, w.npad, J, logdet, info,
-                               g_debug_mask);
+        int nf = 0;
+        if (!leaf_done) {      // (otherwise the previous panel's trailing-update launch factored block J)
+            nf = fill ? fill->take(g_fill_leaf, fa) : 0;
+            if (nf > 0) {
+                hipLaunchKernelGGL((leaf_fill_kernel<T>), dim3(w.q + nf), dim3(256), 0, st, M, W, w.mat, w.npad, J, logdet,
+                                   info, g_debug_mask, w.q, fa);
+            } else {
+                hipLaunchKernelGGL((leaf_kernel<T>), dim3(w.q), dim3(256), 0, st, M, W, w.mat, w.npad, J, logdet, info,
+                                   g_debug_mask);
+            }
+            CHECK_LAUNCH("leaf_kernel");
         }
-        CHECK_LAUNCH("leaf_kernel");
         for (int c = J; c < pe && c + 1 < w.nb; ++c) {
             StepArgs a;
             a.M = M; a.W = W; a.mat = w.mat; a.npad = w.npad; a.nb = w.nb;
@@ -1537,7 +1581,7 @@ int potrf_panel(hipStream_t st, const Ws& w, int J, int pe, Filler* fill = nullp
 
 // trailing update with the panel [J, pe) of the tile columns [c_lo, c_hi) (64-block units, all rows below)
 template <typename T>
-int potrf_trailing(hipStream_t st, const Ws& w, int J, int pe, int c_lo, int c_hi, bool tiles128) {
+int potrf_trailing(hipStream_t st, const Ws& w, int J, int pe, int c_lo, int c_hi, bool tiles128, bool with_leaf = false) {
     if (c_lo >= c_hi) return 0;
     T* M = (T*)(w.base + w.off_M);
     GemmArgs g;
@@ -1547,10 +1591,29 @@ int potrf_trailing(hipStream_t st, const Ws& w, int J, int pe, int c_lo, int c_h
     // a launch with few tiles is bounded by the duration of one tile, which is 4x shorter on 64x64 tiles
     if (tiles128 && (long long)w.q * trapezoid_tiles(w.nb / 2, c_lo / 2, c_hi / 2) >= g_small_tiles_syrk) {
         g.nb = w.nb / 2; g.p0 = J / 2; g.p1 = pe / 2; g.p2 = c_lo / 2; g.p3 = c_hi / 2;
-        return launch_gemm<T, OP_SYRK, 128>(st, g, trapezoid_tiles(w.nb / 2, c_lo / 2, c_hi / 2), w.q);
+        const int nt = trapezoid_tiles(w.nb / 2, c_lo / 2, c_hi / 2);
+        if (with_leaf) {
+            g.q = w.q; g.t0 = 0; g.skipq = 1;
+            hipLaunchKernelGGL((wide_leaf_kernel<T, 128>), dim3((unsigned)(nt + 1) * w.q), dim3(256), 0, st, g, M,
+                               (T*)(w.base + w.off_W), w.mat, w.npad, c_lo, J, (double*)(w.base + w.off_logdet),
+                               (int*)(w.base + w.off_info), g_debug_mask);
+            CHECK_LAUNCH("wide_leaf_kernel");
+            return 0;
+        }
+        return launch_gemm<T, OP_SYRK, 128>(st, g, nt, w.q);
     }
     g.nb = w.nb; g.p0 = J; g.p1 = pe; g.p2 = c_lo; g.p3 = c_hi;
-    return launch_gemm<T, OP_SYRK>(st, g, trapezoid_tiles(w.nb, c_lo, c_hi), w.q);
+    const int nt = trapezoid_tiles(w.nb, c_lo, c_hi);
+    if (with_leaf) {
+        // tile 0 = the diagonal block itself: it belongs to the special workgroups
+        g.q = w.q; g.t0 = 1; g.skipq = 0;
+        hipLaunchKernelGGL((wide_leaf_kernel<T, 64>), dim3((unsigned)nt * w.q), dim3(256), 0, st, g, M,
+                           (T*)(w.base + w.off_W), w.mat, w.npad, c_lo, J, (double*)(w.base + w.off_logdet),
+                           (int*)(w.base + w.off_info), g_debug_mask);
+        CHECK_LAUNCH("wide_leaf_kernel");
+        return 0;
+    }
+    return launch_gemm<T, OP_SYRK>(st, g, nt, w.q);
 }
 
 // Two-level right-looking Cholesky with look-ahead.  Outer panels of `g_outer_blocks` 64-blocks; the trailing
@@ -1575,19 +1638,41 @@ int do_potrf(hipStream_t st, const Ws& w) {
             // columns, which the chain launches of panel J+1 carry as filler tiles (as many as those launches can
             // hide: g_fill_leaf blocks each).
             Filler fill;
-            const int per_panel_blocks = g_step_fused ? g_fill_leaf + (ob - 1) * g_fill_step : ob * g_fill_leaf;
+            bool leaf_done = false;
+            // filler capacity of a panel's chain launches, with and without a diagonal-block launch of its own
+            const int cap_with_leaf = g_step_fused ? g_fill_leaf + (ob - 1) * g_fill_step : ob * g_fill_leaf;
+            const int cap_no_leaf = (ob - 1) * g_fill_step;
             for (int J = 0; J < w.nb; J += ob) {
                 const int pe = J + ob < w.nb ? J + ob : w.nb;
-                int rc = potrf_panel<T>(st, w, J, pe, fill.active() ? &fill : nullptr);
+                int rc = potrf_panel<T>(st, w, J, pe, fill.active() ? &fill : nullptr, leaf_done);
                 if (rc) return rc;
                 if (pe >= w.nb) break;
                 const int mid = pe + ob < w.nb ? pe + ob : w.nb;     // the next panel's own columns are never filler
-                int cf = w.nb;                                         // first filler column
-                if (t128 && per_panel_blocks >= w.q && mid < w.nb) {
-                    const long cap_tiles = per_panel_blocks / w.q;
-                    while (cf - 2 >= mid && rect_tiles(w.nb, cf - 2, w.nb) <= cap_tiles) cf -= 2;
+                auto first_filler_column = [&](int cap_blocks) {
+                    int c = w.nb;
+                    if (t128 && cap_blocks >= w.q && mid < w.nb) {
+                        const long cap_tiles = cap_blocks / w.q;
+                        while (c - 2 >= mid && rect_tiles(w.nb, c - 2, w.nb) <= cap_tiles) c -= 2;
+                    }
+                    return c;
+                };
+                auto wide_on_small_tiles = [&](int c_hi) {
+                    return !(t128 && (long long)w.q * trapezoid_tiles(w.nb / 2, pe / 2, c_hi / 2) >= g_small_tiles_syrk);
+                };
+                int cf = first_filler_column(cap_with_leaf);           // first filler column
+                // When the update runs on 64x64 tiles (few tiles: late panels, few components) it also factors the next
+                // panel's first diagonal block (wide_leaf_kernel).  With many 128x128 tiles that does not pay: the
+                // diagonal-block launch carries filler of its own and the 8-wave tile kernel is the faster one.
+                leaf_done = false;
+                if (g_step_fused && g_leaf_in_wide && wide_on_small_tiles(cf)) {
+                    const int cf3 = first_filler_column(cap_no_leaf);
+                    // (that kernel holds two workgroups per CU, the plain 64-tile kernel four: only launches of one round)
+                    if (wide_on_small_tiles(cf3) && (long long)w.q * trapezoid_tiles(w.nb, pe, cf3) <= g_leaf_in_wide) {
+                        leaf_done = true;
+                        cf = cf3;
+                    }
                 }
-                rc = potrf_trailing<T>(st, w, J, pe, pe, cf, t128);                    // one wide launch
+                rc = potrf_trailing<T>(st, w, J, pe, pe, cf, t128, leaf_done);         // one wide launch
                 if (rc) return rc;
                 fill = Filler();
                 if (cf < w.nb) {                                                       // U2b
@@ -1935,6 +2020,10 @@ int lcgp_set_tuning(int key, int value) {
     }
     if (key == 13) {
         g_fill_step = value;
+        return 0;
+    }
+    if (key == 14) {
+        g_leaf_in_wide = value < 0 ? 0 : value;
         return 0;
     }
     if (key == 10) {

@@ -134,7 +134,7 @@ def test_c_abi_argument_checks():
 
 
 def _reset_tuning(lib):
-    for key, val in ((0, 4), (5, 0), (1, 1), (3, 0), (2, 0), (12, 1), (11, 248), (13, 248)):
+    for key, val in ((0, 4), (5, 0), (1, 1), (3, 0), (2, 0), (12, 1), (11, 248), (13, 248), (14, 1024)):
         lib.lcgp_set_tuning(key, val)
 
 
@@ -149,7 +149,8 @@ def test_tuning_knobs_do_not_change_results():
     lib = _hip.load()
     try:
         for settings in (((0, 2),), ((0, 8),), ((5, 8),), ((1, 2),), ((3, 1),), ((12, 0),), ((2, 4),),
-                         ((12, 0), (2, 4)), ((11, 0), (13, 0)), ((11, 16), (13, 24)), ((0, 3),), ((0, 3), (12, 0))):
+                         ((12, 0), (2, 4)), ((11, 0), (13, 0)), ((11, 16), (13, 24)), ((0, 3),), ((0, 3), (12, 0)), ((14, 0),), ((14, 100000),),
+                         ((14, 100000), (2, 4)), ((14, 100000), (0, 2))):
             for key, val in settings:
                 assert lib.lcgp_set_tuning(key, val) == 0
             v, g = m.loss_and_grad(u)
@@ -169,7 +170,7 @@ def test_chain_variants_match_oracle_at_several_sizes():
             x, y = synth.make_full(seed, n, 2, 6, 2)
             o = orc.OracleLCGP(y=y, x=x, q=2)
             u = synth.param_points(seed, o.get_unconstrained())[1]
-            for settings in ((), ((12, 0),), ((2, 4),)):
+            for settings in ((), ((12, 0),), ((2, 4),), ((14, 0),)):
                 for key, val in settings:
                     assert lib.lcgp_set_tuning(key, val) == 0
                 m = LCGP(y=y, x=x, q=2)
@@ -191,7 +192,7 @@ def _first_bad_pivot(a):
     return 0
 
 
-@pytest.mark.parametrize('variant', [(), ((2, 4),), ((12, 0),)])
+@pytest.mark.parametrize('variant', [(), ((2, 4),), ((12, 0),), ((14, 0),)])
 def test_info_is_the_first_bad_pivot(variant):
     """info of the output block = position of the first non-positive pivot (as LAPACK dpotrf reports it), wherever
     it falls: first block, inside a later 16-column panel of a diagonal block, in a later block or panel."""
