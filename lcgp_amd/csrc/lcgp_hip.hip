@@ -122,12 +122,33 @@ __device__ __forceinline__ const double* th_row(const double* theta, int d, int 
 template <typename T>
 __global__ __launch_bounds__(256) void build_kernel(T* __restrict__ M, size_t mat, int n, int npad, int d, int p,
                                                     const T* __restrict__ x, const T* __restrict__ sr,
-                                                    const double* __restrict__ theta) {
+                                                    const double* __restrict__ theta, int ntile,
+                                                    const T* __restrict__ Y, T* __restrict__ bvec) {
     // arithmetic in the storage type: the float32 variant is the HBM-bound regime (one float exp per element)
     __shared__ T xr[TS][DMAX + 1];
     __shared__ T xc[TS][DMAX + 1];
     __shared__ T srr[TS], src[TS];
     const int k = blockIdx.y;
+    if ((int)blockIdx.x >= ntile) {
+        // blocks past the tiles: b_k[i] = sum_a Y[a, i] psi_k[a]  (lcgp.py:646 + 657-658 collapsed; 608-610 for rep),
+        // independent of the matrix, so it rides in this launch instead of a launch of its own
+        const int i = (blockIdx.x - ntile) * 256 + threadIdx.x;
+        if (i >= npad) return;
+        const double* psi = th_row(theta, d, p, k) + d + 3;
+        double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+        if (i < n) {
+            int a = 0;
+            for (; a + 3 < p; a += 4) {
+                s0 += (double)Y[(size_t)a * n + i] * psi[a];
+                s1 += (double)Y[(size_t)(a + 1) * n + i] * psi[a + 1];
+                s2 += (double)Y[(size_t)(a + 2) * n + i] * psi[a + 2];
+                s3 += (double)Y[(size_t)(a + 3) * n + i] * psi[a + 3];
+            }
+            for (; a < p; ++a) s0 += (double)Y[(size_t)a * n + i] * psi[a];
+        }
+        bvec[(size_t)k * npad + i] = (T)((s0 + s1) + (s2 + s3));
+        return;
+    }
     int r, c;
     tri_decode(blockIdx.x, r, c);
     const double* th = th_row(theta, d, p, k);
@@ -1100,22 +1121,6 @@ __global__ __launch_bounds__(256, 2) void wide_leaf_kernel(GemmArgs g, T* __rest
 }
 
 // ---------------------------------------------------------------------------------------------------
-// b_k[i] = sum_a Y[a, i] psi_k[a]   (lcgp.py:646 + 657-658 collapsed; lcgp.py:608-610 for rep)
-// ---------------------------------------------------------------------------------------------------
-template <typename T>
-__global__ void bvec_kernel(T* __restrict__ b, int n, int npad, int d, int p, const T* __restrict__ Y,
-                            const double* __restrict__ theta) {
-    const int k = blockIdx.y;
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= npad) return;
-    const double* psi = th_row(theta, d, p, k) + d + 3;
-    double s = 0.0;
-    if (i < n)
-        for (int a = 0; a < p; ++a) s += (double)Y[(size_t)a * n + i] * psi[a];
-    b[(size_t)k * npad + i] = (T)s;
-}
-
-// ---------------------------------------------------------------------------------------------------
 // z = A^-1 b with A^-1 stored as lower 64x64 tiles, every tile read ONCE:
 //   symv_tile_kernel : tile (r, c) -> p1 = V_tile b_c (64 values, belongs to z_r) and, off the diagonal,
 //                      p2 = V_tile^T b_r (belongs to z_c); written to the partial buffer [tile][2][64]
@@ -1162,14 +1167,18 @@ __global__ __launch_bounds__(256) void symv_tile_kernel(const T* __restrict__ V,
 }
 
 template <typename T>
-__global__ __launch_bounds__(64) void symv_reduce_kernel(const double* __restrict__ part, int ntile, int npad, int nb,
-                                                         T* __restrict__ z) {
-    const int k = blockIdx.y, R = blockIdx.x, i = threadIdx.x;
+__global__ __launch_bounds__(256) void symv_reduce_kernel(const double* __restrict__ part, int ntile, int npad, int nb,
+                                                          T* __restrict__ z) {
+    // 4 groups of 64 threads take every fourth term; the four partial sums are combined in a fixed order
+    __shared__ double sh[4][TS];
+    const int k = blockIdx.y, R = blockIdx.x, i = threadIdx.x & 63, g = threadIdx.x >> 6;
     const double* pk = part + (size_t)k * ntile * 2 * TS;
     double s = 0.0;
-    for (int c = 0; c <= R; ++c) s += pk[((size_t)(R * (R + 1) / 2 + c)) * 2 * TS + i];
-    for (int r = R + 1; r < nb; ++r) s += pk[((size_t)(r * (r + 1) / 2 + R)) * 2 * TS + TS + i];
-    z[(size_t)k * npad + R * TS + i] = (T)s;
+    for (int c = g; c <= R; c += 4) s += pk[((size_t)(R * (R + 1) / 2 + c)) * 2 * TS + i];
+    for (int r = R + 1 + g; r < nb; r += 4) s += pk[((size_t)(r * (r + 1) / 2 + R)) * 2 * TS + TS + i];
+    sh[g][i] = s;
+    __syncthreads();
+    if (g == 0) z[(size_t)k * npad + R * TS + i] = (T)((sh[0][i] + sh[1][i]) + (sh[2][i] + sh[3][i]));
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -1282,14 +1291,23 @@ __global__ __launch_bounds__(256) void finalize_kernel(int n, int npad, int d, i
     const T* bk = b + (size_t)k * npad;
     const T* zk = z + (size_t)k * npad;
     // tile partials
+    // every load first (one pass over the tile partials, all d + 2 sums at once), then the block reductions
     double sums[DMAX + 2];
-    for (int e = 0; e < d + 2; ++e) {
-        double v = 0.0;
-        for (int t = tid; t < ntile; t += 256) v += part[((size_t)k * ntile + t) * (DMAX + 2) + e];
-        sums[e] = block_sum(v, sh, tid);
+#pragma unroll
+    for (int e = 0; e < DMAX + 2; ++e) sums[e] = 0.0;
+#pragma unroll 4
+    for (int t = tid; t < ntile; t += 256) {
+        const double* pt = part + ((size_t)k * ntile + t) * (DMAX + 2);
+#pragma unroll
+        for (int e = 0; e < DMAX + 2; ++e)
+            if (e < d + 2) sums[e] += pt[e];
     }
     double v = 0.0;
+#pragma unroll 4
     for (int i = tid; i < n; i += 256) v += (double)bk[i] * ((double)bk[i] - (double)zk[i]);
+#pragma unroll
+    for (int e = 0; e < DMAX + 2; ++e)
+        if (e < d + 2) sums[e] = block_sum(sums[e], sh, tid);
     const double quad = block_sum(v, sh, tid);
     const double scale = th[d], nug = th[d + 1];
     const double nt = nug / (1.0 + nug);
@@ -1363,10 +1381,11 @@ __global__ __launch_bounds__(64) void pred_reduce_kernel(const T* __restrict__ X
     } while (0)
 
 template <typename T>
-int do_build(hipStream_t st, const Ws& w, const void* x, const void* sr, const double* theta) {
-    dim3 grid(w.ntile_lower, w.q);
+int do_build(hipStream_t st, const Ws& w, const void* x, const void* sr, const double* theta, const void* Y = nullptr) {
+    // with Y the launch also computes b_k = Y^T psi_k into the workspace (extra blocks past the tiles)
+    dim3 grid(w.ntile_lower + (Y ? (w.npad + 255) / 256 : 0), w.q);
     hipLaunchKernelGGL((build_kernel<T>), grid, dim3(256), 0, st, (T*)(w.base + w.off_M), w.mat, w.n, w.npad, w.d, w.p,
-                       (const T*)x, (const T*)sr, theta);
+                       (const T*)x, (const T*)sr, theta, w.ntile_lower, (const T*)Y, (T*)(w.base + w.off_b));
     CHECK_LAUNCH("build_kernel");
     return 0;
 }
@@ -1893,13 +1912,10 @@ void launch_grad(hipStream_t st, const Ws& w, const void* x, const void* sr, con
 template <typename T>
 int do_nll_grad(hipStream_t st, const Ws& w, const void* x, const void* Y, const void* sr, const double* theta,
                 double* out) {
-    int rc = do_build<T>(st, w, x, sr, theta);
+    int rc = do_build<T>(st, w, x, sr, theta, Y);
     if (rc) return rc;
     T* b = (T*)(w.base + w.off_b);
     T* z = (T*)(w.base + w.off_z);
-    hipLaunchKernelGGL((bvec_kernel<T>), dim3((w.npad + 255) / 256, w.q), dim3(256), 0, st, b, w.n, w.npad, w.d, w.p,
-                       (const T*)Y, theta);
-    CHECK_LAUNCH("bvec_kernel");
     rc = factor_and_invert_triangle<T>(st, w);
     if (rc) return rc;
     rc = do_lauum<T>(st, w);
@@ -1907,7 +1923,7 @@ int do_nll_grad(hipStream_t st, const Ws& w, const void* x, const void* Y, const
     hipLaunchKernelGGL((symv_tile_kernel<T>), dim3(w.ntile_lower, w.q), dim3(256), 0, st, (const T*)(w.base + w.off_V),
                        w.mat, w.npad, (const T*)b, (double*)(w.base + w.off_part), w.ntile_lower);
     CHECK_LAUNCH("symv_tile_kernel");
-    hipLaunchKernelGGL((symv_reduce_kernel<T>), dim3(w.nb, w.q), dim3(64), 0, st, (const double*)(w.base + w.off_part),
+    hipLaunchKernelGGL((symv_reduce_kernel<T>), dim3(w.nb, w.q), dim3(256), 0, st, (const double*)(w.base + w.off_part),
                        w.ntile_lower, w.npad, w.nb, z);
     CHECK_LAUNCH("symv_reduce_kernel");
     if (w.d <= 2) launch_grad<T, 2>(st, w, x, sr, theta);
