@@ -944,6 +944,8 @@ __global__ __launch_bounds__(256) void leaf_fill_kernel(T* __restrict__ M, T* __
 struct StepArgs {
     void* M; void* W; size_t mat; int npad; int nb;
     int c, J, pe;        // this step's column, the panel [J, pe)  (64-block units)
+    int diag_end;        // TRMM tiles of rows < diag_end also update their row's diagonal tile (pe, or pe + 1 when the
+                         // next panel's first diagonal block is factored by the trailing-update launch)
     int q;
     int has_special;     // tile (c+1, c) continues with the diagonal block c+1  (c + 1 < pe)
     int n_trmm;          // TRMM tiles per component INCLUDING the special one: rows c+1 .. nb-1
@@ -1058,7 +1060,7 @@ __global__ __launch_bounds__(256) void chain_step_kernel(StepArgs a) {
         TL::zero(acc);
         TL::template mma<false>(acc, Ct, ld, Wk + (size_t)c * TS * ld + (size_t)c * TS, ld, (T*)lds, tid, lane, wm0, wn0);
         TL::store(acc, Ct, ld, lane, wm0, wn0);         // L[r, c]  (every load of the old tile preceded the mma's barriers)
-        if (r < a.pe) {
+        if (r < a.diag_end) {
             __syncthreads();
             T* Dt = Mk + (size_t)r * TS * ld + (size_t)r * TS;
             TL::load(acc, Dt, ld, lane, wm0, wn0);
@@ -1106,14 +1108,16 @@ __global__ __launch_bounds__(256, 2) void wide_leaf_kernel(GemmArgs g, T* __rest
         const int wm0 = (wave >> 1) * 32, wn0 = (wave & 1) * 32;
         T* Mk = M + (size_t)k * mat;
         T* Dt = Mk + (size_t)jb * TS * npad + (size_t)jb * TS;
-        typename TL::acc_t acc[2][2];
-        TL::load(acc, Dt, npad, lane, wm0, wn0);
-        for (int j = J; j < jb; ++j) {
-            const T* Lt = Mk + (size_t)jb * TS * npad + (size_t)j * TS;
-            TL::template mma<true>(acc, Lt, npad, Lt, npad, (T*)lds, tid, lane, wm0, wn0);
+        if (J < jb) {     // the panel's contribution to the block has not been applied by the chain steps
+            typename TL::acc_t acc[2][2];
+            TL::load(acc, Dt, npad, lane, wm0, wn0);
+            for (int j = J; j < jb; ++j) {
+                const T* Lt = Mk + (size_t)jb * TS * npad + (size_t)j * TS;
+                TL::template mma<true>(acc, Lt, npad, Lt, npad, (T*)lds, tid, lane, wm0, wn0);
+            }
+            TL::store(acc, Dt, npad, lane, wm0, wn0);
+            __syncthreads();
         }
-        TL::store(acc, Dt, npad, lane, wm0, wn0);
-        __syncthreads();
         leaf_body<T>(lds, k, M, W, mat, npad, jb, logdet, info, dbg);
         return;
     }
@@ -1525,7 +1529,8 @@ int g_fill_leaf = 248;    // filler blocks (128x64 tiles) carried by a diagonal-
 // one outer panel [J, pe): per 64-column step  diagonal block -> panel TRMM -> rank-64 update of the rest of the panel;
 // every launch may carry filler tiles
 template <typename T>
-int potrf_panel(hipStream_t st, const Ws& w, int J, int pe, Filler* fill = nullptr, bool leaf_done = false) {
+int potrf_panel(hipStream_t st, const Ws& w, int J, int pe, Filler* fill = nullptr, bool leaf_done = false,
+                bool next_leaf_in_wide = false) {
     T* M = (T*)(w.base + w.off_M);
     T* W = (T*)(w.base + w.off_W);
     double* logdet = (double*)(w.base + w.off_logdet);
@@ -1550,6 +1555,7 @@ int potrf_panel(hipStream_t st, const Ws& w, int J, int pe, Filler* fill = nullp
             StepArgs a;
             a.M = M; a.W = W; a.mat = w.mat; a.npad = w.npad; a.nb = w.nb;
             a.c = c; a.J = J; a.pe = pe; a.q = w.q;
+            a.diag_end = pe + (next_leaf_in_wide ? 1 : 0);
             a.has_special = c + 1 < pe ? 1 : 0;
             a.n_trmm = w.nb - 1 - c;
             a.n_upd = 0;
@@ -1600,7 +1606,8 @@ int potrf_panel(hipStream_t st, const Ws& w, int J, int pe, Filler* fill = nullp
 
 // trailing update with the panel [J, pe) of the tile columns [c_lo, c_hi) (64-block units, all rows below)
 template <typename T>
-int potrf_trailing(hipStream_t st, const Ws& w, int J, int pe, int c_lo, int c_hi, bool tiles128, bool with_leaf = false) {
+int potrf_trailing(hipStream_t st, const Ws& w, int J, int pe, int c_lo, int c_hi, bool tiles128, bool with_leaf = false,
+                   bool diag_preupdated = false) {
     if (c_lo >= c_hi) return 0;
     T* M = (T*)(w.base + w.off_M);
     GemmArgs g;
@@ -1614,7 +1621,7 @@ int potrf_trailing(hipStream_t st, const Ws& w, int J, int pe, int c_lo, int c_h
         if (with_leaf) {
             g.q = w.q; g.t0 = 0; g.skipq = 1;
             hipLaunchKernelGGL((wide_leaf_kernel<T, 128>), dim3((unsigned)(nt + 1) * w.q), dim3(256), 0, st, g, M,
-                               (T*)(w.base + w.off_W), w.mat, w.npad, c_lo, J, (double*)(w.base + w.off_logdet),
+                               (T*)(w.base + w.off_W), w.mat, w.npad, c_lo, diag_preupdated ? c_lo : J, (double*)(w.base + w.off_logdet),
                                (int*)(w.base + w.off_info), g_debug_mask);
             CHECK_LAUNCH("wide_leaf_kernel");
             return 0;
@@ -1627,7 +1634,7 @@ int potrf_trailing(hipStream_t st, const Ws& w, int J, int pe, int c_lo, int c_h
         // tile 0 = the diagonal block itself: it belongs to the special workgroups
         g.q = w.q; g.t0 = 1; g.skipq = 0;
         hipLaunchKernelGGL((wide_leaf_kernel<T, 64>), dim3((unsigned)nt * w.q), dim3(256), 0, st, g, M,
-                           (T*)(w.base + w.off_W), w.mat, w.npad, c_lo, J, (double*)(w.base + w.off_logdet),
+                           (T*)(w.base + w.off_W), w.mat, w.npad, c_lo, diag_preupdated ? c_lo : J, (double*)(w.base + w.off_logdet),
                            (int*)(w.base + w.off_info), g_debug_mask);
         CHECK_LAUNCH("wide_leaf_kernel");
         return 0;
@@ -1663,9 +1670,6 @@ int do_potrf(hipStream_t st, const Ws& w) {
             const int cap_no_leaf = (ob - 1) * g_fill_step;
             for (int J = 0; J < w.nb; J += ob) {
                 const int pe = J + ob < w.nb ? J + ob : w.nb;
-                int rc = potrf_panel<T>(st, w, J, pe, fill.active() ? &fill : nullptr, leaf_done);
-                if (rc) return rc;
-                if (pe >= w.nb) break;
                 const int mid = pe + ob < w.nb ? pe + ob : w.nb;     // the next panel's own columns are never filler
                 auto first_filler_column = [&](int cap_blocks) {
                     int c = w.nb;
@@ -1678,21 +1682,29 @@ int do_potrf(hipStream_t st, const Ws& w) {
                 auto wide_on_small_tiles = [&](int c_hi) {
                     return !(t128 && (long long)w.q * trapezoid_tiles(w.nb / 2, pe / 2, c_hi / 2) >= g_small_tiles_syrk);
                 };
-                int cf = first_filler_column(cap_with_leaf);           // first filler column
+                // decided BEFORE the panel's chain, which then pre-applies the panel to the next diagonal block:
                 // When the update runs on 64x64 tiles (few tiles: late panels, few components) it also factors the next
                 // panel's first diagonal block (wide_leaf_kernel).  With many 128x128 tiles that does not pay: the
                 // diagonal-block launch carries filler of its own and the 8-wave tile kernel is the faster one.
-                leaf_done = false;
-                if (g_step_fused && g_leaf_in_wide && wide_on_small_tiles(cf)) {
-                    const int cf3 = first_filler_column(cap_no_leaf);
-                    // (that kernel holds two workgroups per CU, the plain 64-tile kernel four: only launches of one round)
-                    if (wide_on_small_tiles(cf3) && (long long)w.q * trapezoid_tiles(w.nb, pe, cf3) <= g_leaf_in_wide) {
-                        leaf_done = true;
-                        cf = cf3;
+                int cf = w.nb;                                         // first filler column
+                bool next_leaf = false;
+                if (pe < w.nb) {
+                    cf = first_filler_column(cap_with_leaf);
+                    if (g_step_fused && g_leaf_in_wide && wide_on_small_tiles(cf)) {
+                        const int cf3 = first_filler_column(cap_no_leaf);
+                        // (that kernel holds two workgroups per CU, the plain 64-tile kernel four: launches of few rounds)
+                        if (wide_on_small_tiles(cf3) && (long long)w.q * trapezoid_tiles(w.nb, pe, cf3) <= g_leaf_in_wide) {
+                            next_leaf = true;
+                            cf = cf3;
+                        }
                     }
                 }
-                rc = potrf_trailing<T>(st, w, J, pe, pe, cf, t128, leaf_done);         // one wide launch
+                int rc = potrf_panel<T>(st, w, J, pe, fill.active() ? &fill : nullptr, leaf_done, next_leaf);
                 if (rc) return rc;
+                if (pe >= w.nb) break;
+                rc = potrf_trailing<T>(st, w, J, pe, pe, cf, t128, next_leaf, next_leaf);   // one wide launch
+                if (rc) return rc;
+                leaf_done = next_leaf;
                 fill = Filler();
                 if (cf < w.nb) {                                                       // U2b
                     GemmArgs& f = fill.f;
