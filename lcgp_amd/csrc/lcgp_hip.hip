@@ -1673,9 +1673,13 @@ int do_potrf(hipStream_t st, const Ws& w) {
                 const int mid = pe + ob < w.nb ? pe + ob : w.nb;     // the next panel's own columns are never filler
                 auto first_filler_column = [&](int cap_blocks) {
                     int c = w.nb;
-                    if (t128 && cap_blocks >= w.q && mid < w.nb) {
+                    // filler rides on the chain launches of the NEXT panel [pe, mid): it must stay clear of that panel's
+                    // columns and, when those chain steps pre-apply the panel to the diagonal block (mid, mid) for a
+                    // trailing-update launch that factors it, of column `mid` too
+                    const int lo = mid + (g_step_fused && g_leaf_in_wide ? 2 : 0);
+                    if (t128 && cap_blocks >= w.q && lo < w.nb) {
                         const long cap_tiles = cap_blocks / w.q;
-                        while (c - 2 >= mid && rect_tiles(w.nb, c - 2, w.nb) <= cap_tiles) c -= 2;
+                        while (c - 2 >= lo && rect_tiles(w.nb, c - 2, w.nb) <= cap_tiles) c -= 2;
                     }
                     return c;
                 };
