@@ -134,7 +134,7 @@ def test_c_abi_argument_checks():
 
 
 def _reset_tuning(lib):
-    for key, val in ((0, 4), (5, 0), (1, 1), (3, 0), (2, 0), (12, 1), (11, 248), (13, 248), (14, 1024)):
+    for key, val in ((0, 4), (5, 0), (1, 1), (3, 0), (2, 0), (12, 1), (11, 248), (13, 248), (14, 1024), (8, 2000)):
         lib.lcgp_set_tuning(key, val)
 
 
@@ -151,6 +151,28 @@ def test_tuning_knobs_do_not_change_results():
         for settings in (((0, 2),), ((0, 8),), ((5, 8),), ((1, 2),), ((3, 1),), ((12, 0),), ((2, 4),),
                          ((12, 0), (2, 4)), ((11, 0), (13, 0)), ((11, 16), (13, 24)), ((0, 3),), ((0, 3), (12, 0)), ((14, 0),), ((14, 100000),),
                          ((14, 100000), (2, 4)), ((14, 100000), (0, 2))):
+            for key, val in settings:
+                assert lib.lcgp_set_tuning(key, val) == 0
+            v, g = m.loss_and_grad(u)
+            assert abs(v - ref_v) <= 1e-11 * abs(ref_v), settings
+            assert np.max(np.abs(g - ref_g)) <= 1e-10 * np.max(np.abs(ref_g)), settings
+            _reset_tuning(lib)
+    finally:
+        _reset_tuning(lib)
+
+
+def test_wide_tile_schedules_agree_at_medium_size():
+    """Forces the 128x128-tile trailing update with filler tiles on a problem small enough for a unit test (the default
+    thresholds only use it from ~n = 3000 on) and compares every chain variant with the default schedule: the
+    transitions 128-tile update -> 64-tile update that also factors the next diagonal block -> no update are all hit."""
+    x, y = synth.make_full(327, 1500, 3, 5, 4)
+    m = LCGP(y=y, x=x, q=4)
+    u = synth.param_points(327, m._get_flat())[1]
+    ref_v, ref_g = m.loss_and_grad(u)
+    lib = _hip.load()
+    try:
+        for settings in (((8, 16),), ((8, 16), (14, 0)), ((8, 16), (12, 0)), ((8, 16), (14, 100000)), ((8, 16), (11, 40), (13, 56)),
+                         ((8, 16), (0, 2)), ((8, 16), (0, 8)), ((8, 200), (14, 300)), ((8, 16), (2, 4))):
             for key, val in settings:
                 assert lib.lcgp_set_tuning(key, val) == 0
             v, g = m.loss_and_grad(u)
