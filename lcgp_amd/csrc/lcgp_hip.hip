@@ -935,8 +935,8 @@ __global__ __launch_bounds__(256) void leaf_fill_kernel(T* __restrict__ M, T* __
 //     (so the panel's diagonal tiles have exactly one writer per launch);
 //   * the tile (c+1, c) is "special": after the two steps above its workgroup factors and inverts the diagonal
 //     block c+1 (leaf_body), which is what launch X_{c+1} needs;
-//   * delayed updates: column c-1 applied to the tiles (r, c'), c < c' < panel end, r > c'  (strictly below the
-//     diagonal; column c-1 became final in X_{c-1});
+//   * delayed updates, one visit per tile: the tiles (r, c+1), r > c+1, of the next column receive the columns
+//     J .. c-1 in one K loop (all of them final before this launch; column c is folded into the next step's TRMM);
 //   * filler tiles of the previous panel's trailing update (syrk_rect_body) as before.
 // Per panel of 4 columns: 1 diagonal-block launch + 4 step launches instead of 12 launches, and the chain of a step
 // is  2-3 K=64 products + one diagonal block  on a single workgroup.
@@ -1074,17 +1074,19 @@ __global__ __launch_bounds__(256) void chain_step_kernel(StepArgs a) {
         return;
     }
     {
+        // delayed update, one visit per tile: the tiles (r, c + 1), r > c + 1, of the NEXT column receive the columns
+        // J .. c-1 in one K loop (column c itself is folded into the next step's TRMM tiles)
         k = b % a.q;
         t = b / a.q;
-        int cc = a.c + 1;
-        while (t >= a.nb - cc - 1) { t -= a.nb - cc - 1; ++cc; }
-        const int r = cc + 1 + t, j = a.c - 1;
+        const int cc = a.c + 1;
+        const int r = cc + 1 + t;
         T* Mk = (T*)a.M + (size_t)k * a.mat;
         T* Ct = Mk + (size_t)r * TS * ld + (size_t)cc * TS;
         typename TL::acc_t acc[2][2];
         TL::load(acc, Ct, ld, lane, wm0, wn0);
-        TL::template mma<true>(acc, Mk + (size_t)r * TS * ld + (size_t)j * TS, ld,
-                               Mk + (size_t)cc * TS * ld + (size_t)j * TS, ld, (T*)lds, tid, lane, wm0, wn0);
+        for (int j = a.J; j < a.c; ++j)
+            TL::template mma<true>(acc, Mk + (size_t)r * TS * ld + (size_t)j * TS, ld,
+                                   Mk + (size_t)cc * TS * ld + (size_t)j * TS, ld, (T*)lds, tid, lane, wm0, wn0);
         TL::store(acc, Ct, ld, lane, wm0, wn0);
     }
 }
@@ -1559,8 +1561,7 @@ int potrf_panel(hipStream_t st, const Ws& w, int J, int pe, Filler* fill = nullp
             a.has_special = c + 1 < pe ? 1 : 0;
             a.n_trmm = w.nb - 1 - c;
             a.n_upd = 0;
-            if (c > J)
-                for (int cc = c + 1; cc < pe; ++cc) a.n_upd += w.nb - cc - 1;
+            if (c > J && c + 1 < pe) a.n_upd = w.nb - (c + 1) - 1;     // the tiles below the diagonal of column c + 1
             a.logdet = logdet; a.info = info; a.dbg = g_debug_mask;
             nf = (fill && a.has_special) ? fill->take(g_fill_step, fa) : 0;
             a.f = fa; a.nfill = nf;
