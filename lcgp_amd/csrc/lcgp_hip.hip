@@ -170,32 +170,51 @@ __global__ __launch_bounds__(256) void build_kernel(T* __restrict__ M, size_t ma
     }
     __syncthreads();
     T* Mk = M + (size_t)k * mat;
-    const int j = tid & 63;
-    const int gj = c * TS + j;
-    T xcj[DMAX];
+    // 4 x 4 elements per thread (16 x 16 threads per tile): every LDS read of a scaled input row/column is used four
+    // times, 16 independent exp chains per thread, and each thread stores four 4-element row segments (a wave writes
+    // whole 512-byte row pieces in fp64)
+    const int tx = tid & 15, ty = tid >> 4;
+    const int i0 = ty * 4, j0 = tx * 4;
+    T poly[4][4], ssum[4][4];
 #pragma unroll
-    for (int jj = 0; jj < DMAX; ++jj) xcj[jj] = jj < d ? xc[j][jj] : (T)0;
-    for (int m = 0; m < 16; ++m) {
-        const int i = (tid >> 6) * 16 + m;
-        const int gi = r * TS + i;
-        T v;
-        if (gi < n && gj < n) {
-            T poly = 1, ssum = 0;
+    for (int a = 0; a < 4; ++a)
 #pragma unroll
-            for (int jj = 0; jj < DMAX; ++jj) {
-                if (jj < d) {
-                    T s = fabs(xr[i][jj] - xcj[jj]);
-                    poly *= (T)1 + s;
-                    ssum -= s;
+        for (int b = 0; b < 4; ++b) { poly[a][b] = (T)1; ssum[a][b] = (T)0; }
+#pragma unroll
+    for (int jj = 0; jj < DMAX; ++jj) {
+        if (jj < d) {
+            T xa[4], xb[4];
+#pragma unroll
+            for (int a = 0; a < 4; ++a) { xa[a] = xr[i0 + a][jj]; xb[a] = xc[j0 + a][jj]; }
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    const T sd = fabs(xa[a] - xb[b]);
+                    poly[a][b] = fma(poly[a][b], sd, poly[a][b]);
+                    ssum[a][b] -= sd;
                 }
-            }
-            T c0 = poly * exp(ssum);
-            v = srr[i] * src[j] * c_off * c0;
-            if (gi == gj) v += (T)1 + (c_diag - (T)1) * srr[i] * src[j];
-        } else {
-            v = gi == gj ? (T)1 : (T)0;
         }
-        Mk[(size_t)gi * npad + gj] = v;
+    }
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        const int gi = r * TS + i0 + a;
+        T v[4];
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const int gj = c * TS + j0 + b;
+            if (gi < n && gj < n) {
+                const T c0 = poly[a][b] * exp(ssum[a][b]);
+                const T ss = srr[i0 + a] * src[j0 + b];
+                v[b] = ss * c_off * c0;
+                if (gi == gj) v[b] += (T)1 + (c_diag - (T)1) * ss;
+            } else {
+                v[b] = gi == gj ? (T)1 : (T)0;
+            }
+        }
+        T* dst = Mk + (size_t)gi * npad + c * TS + j0;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) dst[b] = v[b];
     }
 }
 
