@@ -56,7 +56,7 @@ int lcgp_out_width(int d, int p);
  *   key 5: width of the Cholesky super-panel in 64-column blocks (default 0 = the panel width, i.e. off): trailing updates of the panels stop at
  *          the super-panel boundary, the rest of the matrix is updated once per super-panel;
  *   key 6 / key 7: below this many 128x128 tiles per launch (components x tiles) the triangular inverse (6, default
- *          4200) / A^-1 = W^T W (7, default 1024) run on 64x64 tiles: with few components a launch is bounded by
+ *          4200) / A^-1 = W^T W (7, default 2048) run on 64x64 tiles: with few components a launch is bounded by
  *          its longest tile (0 = always 128x128);
  *   key 8: the same switch for the trailing update of the Cholesky (default 2000);
  *   key 11: filler blocks (128x64 tiles of the previous panel's trailing update) carried by each diagonal-block launch

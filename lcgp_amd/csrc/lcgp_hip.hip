@@ -1822,7 +1822,7 @@ int do_potrf(hipStream_t st, const Ws& w) {
 // K = 4096 keeps a CU busy for ~0.5 ms while the rest of the chip idles): below `g_small_tiles` 128-tiles per
 // launch the same products run on 64x64 tiles (4x more, 4x shorter tiles).  lcgp_set_tuning key 6.
 int g_small_tiles_trtri = 4200;   // measured at n=4096: 64-tiles win for q_local <= 4, lose at 8
-int g_small_tiles_lauum = 1024;   //                      64-tiles win for q_local = 1 only
+int g_small_tiles_lauum = 2048;   //                      64-tiles win for q_local <= 3
 
 inline bool use_small_tiles(const Ws& w, int threshold) {
     const int nb2 = w.nb / 2;
