@@ -243,3 +243,34 @@ def test_info_is_the_first_bad_pivot(variant):
     finally:
         _reset_tuning(lib)
     assert [int(r[2]) for r in out] == want
+
+
+def test_random_shapes_and_schedules_against_oracle():
+    """Seeded sweep: random (n, d, p, q) with a random schedule variant each, NLL and gradient against the oracle.
+    (sizes up to a few panels; the tolerances are the parity bar of the path: 1e-6 / 1e-5 relative)"""
+    rng = np.random.default_rng(20260401)
+    lib = _hip.load()
+    variants = [(), ((12, 0),), ((2, 4),), ((14, 0),), ((14, 100000),), ((0, 2),), ((0, 3),), ((0, 8),), ((11, 8), (13, 16)),
+                ((8, 1),), ((8, 1), (14, 100000)), ((8, 1), (11, 24), (13, 40))]
+    try:
+        for case in range(14):
+            n = int(rng.integers(1, 3)) if case == 0 else int(rng.integers(2, 1100))
+            d = int(rng.integers(1, 5))
+            p = int(rng.integers(1, 7))
+            q = int(rng.integers(1, min(p, 3) + 1))
+            seed = 5000 + case
+            x, y = synth.make_full(seed, max(n, 2), d, p, q)
+            kw = dict(q=q, robust_mean=n > 8)
+            o = orc.OracleLCGP(y=y, x=x, **kw)
+            u = synth.param_points(seed, o.get_unconstrained())[1 if n > 8 else 0]
+            settings = variants[int(rng.integers(0, len(variants)))]
+            for key, val in settings:
+                assert lib.lcgp_set_tuning(key, val) == 0
+            m = LCGP(y=y, x=x, **kw)
+            try:
+                _same(m, o, u)
+            except AssertionError as e:
+                raise AssertionError('case %d: n=%d d=%d p=%d q=%d settings=%r: %s' % (case, n, d, p, q, settings, e))
+            _reset_tuning(lib)
+    finally:
+        _reset_tuning(lib)
