@@ -790,29 +790,32 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, const int lin /*blo
         }
     }
     if (!done) {
-        // register prefetch TWO stages ahead (the loads of stage s+2 are issued while stage s is multiplied): with
-        // few workgroups per CU one stage of MFMAs (~0.5 us) does not cover an HBM/L2 round trip
-        T ra[2][EPT], rb[2][EPT];
-        load_stage<T, LA, TM, NT>(A0, g.ldA, 0, ra[0], tid);
-        load_stage<T, LB, TM, NT>(B0, g.ldB, 0, rb[0], tid);
-        if (nst > 1) {
-            const int kt = 1 / SPT, ks = (1 % SPT) * KT;
-            load_stage<T, LA, TM, NT>(A0 + (ptrdiff_t)kt * dA, g.ldA, ks, ra[1], tid);
-            load_stage<T, LB, TM, NT>(B0 + (ptrdiff_t)kt * dB, g.ldB, ks, rb[1], tid);
-        }
-        for (int s = 0; s < nst; s += 2) {
+        // register prefetch PF stages ahead (the loads of stage s+PF are issued while stage s is multiplied): with
+        // few workgroups per CU one stage of MFMAs (~0.5 us) does not cover an HBM/L2 round trip; the 64-tile kernel,
+        // whose launches are often a fraction of a round, looks a whole k tile ahead
+        constexpr int PF = (TM == 64 && OP != OP_SYRK) ? 4 : 2;   // (the rank-k update holds its C tile too: 4 would spill)
+        T ra[PF][EPT], rb[PF][EPT];
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {        // h = (s + h) & 1: static register / buffer index
+        for (int h = 0; h < PF; ++h) {
+            if (h < nst) {
+                const int kt = h / SPT, ks = (h % SPT) * KT;
+                load_stage<T, LA, TM, NT>(A0 + (ptrdiff_t)kt * dA, g.ldA, ks, ra[h], tid);
+                load_stage<T, LB, TM, NT>(B0 + (ptrdiff_t)kt * dB, g.ldB, ks, rb[h], tid);
+            }
+        }
+        for (int s = 0; s < nst; s += PF) {
+#pragma unroll
+            for (int h = 0; h < PF; ++h) {       // (s + h) & 1 == h & 1: static register / buffer index
                 if (s + h < nst) {
-                    store_stage<T, LA, TM, NT>(As + h * KT * LD, ra[h], tid);
-                    store_stage<T, LB, TM, NT>(Bs + h * KT * LD, rb[h], tid);
+                    store_stage<T, LA, TM, NT>(As + (h & 1) * KT * LD, ra[h], tid);
+                    store_stage<T, LB, TM, NT>(Bs + (h & 1) * KT * LD, rb[h], tid);
                     __syncthreads();
-                    if (s + h + 2 < nst) {
-                        const int kt = (s + h + 2) / SPT, ks = ((s + h + 2) % SPT) * KT;
+                    if (s + h + PF < nst) {
+                        const int kt = (s + h + PF) / SPT, ks = ((s + h + PF) % SPT) * KT;
                         load_stage<T, LA, TM, NT>(A0 + (ptrdiff_t)kt * dA, g.ldA, ks, ra[h], tid);
                         load_stage<T, LB, TM, NT>(B0 + (ptrdiff_t)kt * dB, g.ldB, ks, rb[h], tid);
                     }
-                    compute_stage(h);
+                    compute_stage(h & 1);
                 }
             }
         }
