@@ -52,7 +52,7 @@ int lcgp_theta_width(int d, int p);
 int lcgp_out_width(int d, int p);
 
 /* performance knobs (process-wide, for experiments; results do not depend on them beyond rounding):
- *   key 0: width of the outer Cholesky panel in 64-column blocks (default 4);
+ *   key 0: width of the outer Cholesky panel in 64-column blocks (default 0 = automatic: 4 in fp64, 8 in fp32);
  *   key 5: width of the Cholesky super-panel in 64-column blocks (default 0 = the panel width, i.e. off): trailing updates of the panels stop at
  *          the super-panel boundary, the rest of the matrix is updated once per super-panel;
  *   key 6 / key 7: below this many 128x128 tiles per launch (components x tiles) the triangular inverse (6, default

@@ -1489,7 +1489,8 @@ int pool_get(StreamPool*& out) {
     return 0;
 }
 
-int g_outer_blocks = 4;   // width of the outer Cholesky panel in 64-blocks (lcgp_set_tuning key 0)
+int g_outer_blocks = 0;   // width of the outer Cholesky panel in 64-blocks (lcgp_set_tuning key 0); 0 = automatic: 4 in fp64,
+                          // 8 in fp32 (twice the MFMA rate per byte of read-modify-write traffic; measured at n = 4096 .. 16384)
 int g_super_blocks = 0;   // width of the Cholesky super-panel in 64-blocks (lcgp_set_tuning key 5); 0 = same as the panel
                           // (measured: 8, 16, 32 are not faster at n=4096)
 int g_debug_mask = 0;     // lcgp_set_tuning key 2: 1 = skip pivots, 2 = skip inverse (timing experiments only, wrong results);
@@ -1676,7 +1677,7 @@ int do_potrf(hipStream_t st, const Ws& w) {
     int* info = (int*)(w.base + w.off_info);
     hipLaunchKernelGGL(zero_stats_kernel, dim3((w.q + 63) / 64), dim3(64), 0, st, logdet, info, w.q);
     CHECK_LAUNCH("zero_stats");
-    const int ob = g_outer_blocks < 1 ? 1 : g_outer_blocks;
+    const int ob = g_outer_blocks < 1 ? (sizeof(T) == 4 ? 8 : 4) : g_outer_blocks;
     const bool t128 = (ob & 1) == 0;
     if (!g_lookahead || w.nb <= ob) {
         int sb = g_super_blocks < ob ? ob : g_super_blocks;
@@ -2041,7 +2042,7 @@ int lcgp_out_width(int d, int p) { return d + 5 + p; }
 
 int lcgp_set_tuning(int key, int value) {
     if (key == 0) {
-        if (value < 1 || value > 64) return bad("outer panel width must be in [1, 64] blocks");
+        if (value < 0 || value > 64) return bad("outer panel width must be in [0, 64] blocks (0 = automatic)");
         g_outer_blocks = value;
         return 0;
     }

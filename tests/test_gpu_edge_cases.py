@@ -131,10 +131,11 @@ def test_c_abi_argument_checks():
     assert b'NULL' in lib.lcgp_last_error()
     assert lib.lcgp_set_tuning(99, 1) < 0
     assert lib.lcgp_set_tuning(0, 4) == 0
+    assert lib.lcgp_set_tuning(0, 0) == 0
 
 
 def _reset_tuning(lib):
-    for key, val in ((0, 4), (5, 0), (1, 1), (3, 0), (2, 0), (12, 1), (11, 248), (13, 248), (14, 1024), (8, 2000)):
+    for key, val in ((0, 0), (5, 0), (1, 1), (3, 0), (2, 0), (12, 1), (11, 248), (13, 248), (14, 1024), (8, 2000)):
         lib.lcgp_set_tuning(key, val)
 
 
