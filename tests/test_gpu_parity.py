@@ -196,6 +196,20 @@ def test_cfg3_directional_derivative(cfg3):
     assert abs(fd - g @ dirn) <= 1e-5 * max(1.0, abs(g @ dirn)), (fd, g @ dirn)
 
 
+def test_cfg3_repeated_evaluations_are_bitwise_identical(cfg3):
+    """Every reduction of the path has a fixed order and no launch contains a read-modify-write race: the same
+    parameters give the same bits, evaluation after evaluation (a race between filler tiles and the chain would show
+    up here as run-to-run noise)."""
+    x, y, cfg, m = cfg3
+    u = synth.param_points(3, m._get_flat())[2]
+    v0, g0 = m.loss_and_grad(u)
+    for _ in range(4):
+        m.loss_and_grad(m._get_flat() * 0 + synth.param_points(3, u)[0])      # another point in between
+        v, g = m.loss_and_grad(u)
+        assert v == v0
+        assert np.array_equal(g, g0)
+
+
 def test_cfg3_inverse_times_matrix_is_identity_on_sampled_columns(cfg3):
     x, y, cfg, m = cfg3
     m.loss_and_grad(m._get_flat())

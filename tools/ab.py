@@ -20,14 +20,20 @@ DEFAULTS = {0: 0, 1: 1, 2: 0, 3: 0, 5: 0, 6: 4200, 7: 2048, 8: 2000, 9: 8, 10: 0
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--q', type=int, default=8)
-    ap.add_argument('--n', type=int, default=4096)
+    ap.add_argument('--n', type=int, default=None)
+    ap.add_argument('--config', type=int, default=3, help='BASELINE.json configuration (3 = headline fp64, 4 = fp32 n=16384)')
     ap.add_argument('--reps', type=int, default=4)
     ap.add_argument('--steps', type=int, default=6)
     ap.add_argument('settings', nargs='+')
     a = ap.parse_args()
-    x, y, cfg = synth.make_config(3)
-    x, y = x[:a.n], y[:, :a.n]
-    m = LCGP(y=y, x=x, q=a.q)          # q components = one rank's share of the headline configuration
+    x, y, cfg = synth.make_config(a.config)
+    if cfg['submethod'] != 'full':
+        raise SystemExit('ab.py times the full path only')
+    if a.n:
+        x, y = x[:a.n], y[:, :a.n]
+    a.n = x.shape[0]
+    dtype = 'float64' if cfg['dtype'] == 'f64' else 'float32'
+    m = LCGP(y=y, x=x, q=a.q, dtype=dtype)          # q components = one rank's share of the configuration
     lib = _hip.load()
     u = m._get_flat()
     eng = None
