@@ -36,10 +36,8 @@ def local_components(q: int, rank: int, world: int):
     return list(range(rank, q, world))
 
 
-def all_reduce_sum(vec, group=None, device=None):
-    """Sum a float64 numpy vector over the ranks (returns a new numpy array, identical on all ranks)."""
-    if not is_distributed(group):
-        return np.asarray(vec, np.float64)
+def _all_reduce_impl(vec, group=None, device=None):
+    """The collective itself (also exercised on a 1-rank RCCL group by tests/test_gpu_api.py)."""
     import torch
     dist = _dist()
     t = torch.as_tensor(np.ascontiguousarray(vec, np.float64))
@@ -48,6 +46,13 @@ def all_reduce_sum(vec, group=None, device=None):
         t = t.to(device if device is not None else torch.device("cuda", torch.cuda.current_device()))
     dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
     return t.cpu().numpy()
+
+
+def all_reduce_sum(vec, group=None, device=None):
+    """Sum a float64 numpy vector over the ranks (returns a new numpy array, identical on all ranks)."""
+    if not is_distributed(group):
+        return np.asarray(vec, np.float64)
+    return _all_reduce_impl(vec, group, device)
 
 
 def gather_rows(local_rows, q: int, group=None, device=None):
@@ -65,10 +70,7 @@ def gather_rows(local_rows, q: int, group=None, device=None):
     return all_reduce_sum(full.reshape(-1), group, device).reshape(q, m)
 
 
-def broadcast_array(arr, src=0, group=None, device=None):
-    """Every rank returns rank `src`'s float64 array (used so that all ranks share ONE SVD basis)."""
-    if not is_distributed(group):
-        return np.asarray(arr, np.float64)
+def _broadcast_impl(arr, src=0, group=None, device=None):
     import torch
     dist = _dist()
     t = torch.as_tensor(np.ascontiguousarray(arr, np.float64)).clone()
@@ -76,3 +78,10 @@ def broadcast_array(arr, src=0, group=None, device=None):
         t = t.to(device if device is not None else torch.device("cuda", torch.cuda.current_device()))
     dist.broadcast(t, src=dist.get_global_rank(group, src) if group is not None else src, group=group)
     return t.cpu().numpy()
+
+
+def broadcast_array(arr, src=0, group=None, device=None):
+    """Every rank returns rank `src`'s float64 array (used so that all ranks share ONE SVD basis)."""
+    if not is_distributed(group):
+        return np.asarray(arr, np.float64)
+    return _broadcast_impl(arr, src, group, device)

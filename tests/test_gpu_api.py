@@ -79,3 +79,31 @@ def test_second_fit_invalidates_prediction_caches():
     model.fit()
     p1 = model.predict(x[:5])[0].numpy()
     assert np.max(np.abs(p0 - p1)) > 1e-8
+
+
+def test_rccl_collectives_on_a_one_rank_group():
+    """The N > 1 bench runs over RCCL (backend "nccl"), which this one-GPU box cannot form with several ranks; a 1-rank
+    RCCL group still goes through the same code: host vector -> device -> all_reduce / broadcast -> host."""
+    import os
+    import tempfile
+    import torch
+    import torch.distributed as dist
+    from lcgp_amd import dist as ldist
+    if dist.is_initialized():
+        pytest.skip('a process group already exists in this process')
+    store = tempfile.NamedTemporaryFile(delete=False)
+    store.close()
+    try:
+        dist.init_process_group('nccl', init_method='file://' + store.name, rank=0, world_size=1,
+                                device_id=torch.device('cuda', torch.cuda.current_device()))
+        v = np.arange(131, dtype=np.float64) / 7.0
+        got = ldist._all_reduce_impl(v)
+        assert got.dtype == np.float64 and np.array_equal(got, v)
+        got = ldist._broadcast_impl(v.reshape(1, -1), 0)
+        assert got.shape == (1, 131) and np.array_equal(got.ravel(), v)
+        dist.barrier()
+    finally:
+        if dist.is_initialized():
+            dist.destroy_process_group()
+        if os.path.exists(store.name):
+            os.unlink(store.name)
