@@ -67,6 +67,8 @@ int lcgp_out_width(int d, int p);
  *   key 13: filler blocks carried by each chain-step launch that ends in a diagonal block (default 248);
  *   key 14: a trailing-update launch of at most this many 64x64 tiles (x components) also factors the next panel's
  *          first diagonal block, so that panel's chain starts one launch earlier (default 1024; 0 = never);
+ *   key 15: a level of the triangular inverse with fewer than this many 128x128 tiles (x components) runs on 64x64
+ *          tiles even when the large levels use 128x128 ones (default 600);
  *   key 2: bit 2 (value 4) = barrier-per-pivot-pair variant of the diagonal-block kernel instead of the in-wave
  *          16-column panels (bits 0 and 1 skip work for timing experiments and give wrong results);
  *   key 3: 1 = look-ahead Cholesky (panel chain on an internal stream), 0 (default) = single stream;

@@ -1834,41 +1834,39 @@ inline bool use_small_tiles(const Ws& w, int threshold) {
 }
 
 template <typename T, int TM>
-int trtri_levels(hipStream_t st, const Ws& w, int first_mb) {
-    T* M = (T*)(w.base + w.off_M);
-    T* W = (T*)(w.base + w.off_W);
-    T* V = (T*)(w.base + w.off_V);
+int trtri_level(hipStream_t st, const Ws& w, int mb) {      // one level: pairs of blocks of mb tiles (TM units)
     GemmArgs g;
     g.sA = g.sB = g.sC = w.mat; g.ldA = g.ldB = g.ldC = w.npad; g.p2 = g.p3 = 0;
     const int nbt = w.npad / TM;
     g.nb = nbt;
-    for (int mb = first_mb; mb < nbt; mb *= 2) {
-        const int pairs = (nbt + 2 * mb - 1) / (2 * mb);
-        g.p0 = mb; g.p1 = pairs;
-        g.A = M; g.B = W; g.C = V;
-        int rc = launch_gemm<T, OP_TRTRI_T, TM>(st, g, pairs * mb * mb, w.q);
-        if (rc) return rc;
-        g.A = W; g.B = V; g.C = W;
-        rc = launch_gemm<T, OP_TRTRI_W, TM>(st, g, pairs * mb * mb, w.q);
-        if (rc) return rc;
-    }
-    return 0;
+    const int pairs = (nbt + 2 * mb - 1) / (2 * mb);
+    g.p0 = mb; g.p1 = pairs;
+    g.A = (T*)(w.base + w.off_M); g.B = (T*)(w.base + w.off_W); g.C = (T*)(w.base + w.off_V);
+    int rc = launch_gemm<T, OP_TRTRI_T, TM>(st, g, pairs * mb * mb, w.q);
+    if (rc) return rc;
+    g.A = (T*)(w.base + w.off_W); g.B = (T*)(w.base + w.off_V); g.C = (T*)(w.base + w.off_W);
+    return launch_gemm<T, OP_TRTRI_W, TM>(st, g, pairs * mb * mb, w.q);
 }
+
+int g_trtri_level_small = 600;  // lcgp_set_tuning key 15: a level with fewer 128x128 tiles (x components) than this runs on 64x64
+                               // tiles even when the large levels use 128x128 ones
 
 template <typename T>
 int do_trtri(hipStream_t st, const Ws& w) {
-    if (use_small_tiles(w, g_small_tiles_trtri)) return trtri_levels<T, 64>(st, w, 1);
-    // level 0 joins pairs of 64-blocks (64x64 tiles); every further level works on 128x128 tiles
-    GemmArgs g;
-    g.sA = g.sB = g.sC = w.mat; g.ldA = g.ldB = g.ldC = w.npad; g.p2 = g.p3 = 0;
-    g.nb = w.nb; g.p0 = 1; g.p1 = w.nb / 2;
-    g.A = (T*)(w.base + w.off_M); g.B = (T*)(w.base + w.off_W); g.C = (T*)(w.base + w.off_V);
-    int rc = launch_gemm<T, OP_TRTRI_T, 64>(st, g, w.nb / 2, w.q);
-    if (rc) return rc;
-    g.A = (T*)(w.base + w.off_W); g.B = (T*)(w.base + w.off_V); g.C = (T*)(w.base + w.off_W);
-    rc = launch_gemm<T, OP_TRTRI_W, 64>(st, g, w.nb / 2, w.q);
-    if (rc) return rc;
-    return trtri_levels<T, 128>(st, w, 1);
+    const bool all_small = use_small_tiles(w, g_small_tiles_trtri);
+    // levels in 64-block units: mb64 = 1 joins pairs of 64-blocks (always 64x64 tiles); a further level works on 128x128
+    // tiles unless the whole inverse or this level is too small to fill the chip with them
+    for (int mb64 = 1; mb64 < w.nb; mb64 *= 2) {
+        bool small = all_small || mb64 == 1;
+        if (!small) {
+            const int mb = mb64 / 2, nbt = w.npad / 128;
+            const long long tiles = (long long)((nbt + 2 * mb - 1) / (2 * mb)) * mb * mb * w.q;
+            small = tiles < g_trtri_level_small;
+        }
+        const int rc = small ? trtri_level<T, 64>(st, w, mb64) : trtri_level<T, 128>(st, w, mb64 / 2);
+        if (rc) return rc;
+    }
+    return 0;
 }
 
 template <typename T>
@@ -2080,6 +2078,10 @@ int lcgp_set_tuning(int key, int value) {
     }
     if (key == 14) {
         g_leaf_in_wide = value < 0 ? 0 : value;
+        return 0;
+    }
+    if (key == 15) {
+        g_trtri_level_small = value < 0 ? 0 : value;
         return 0;
     }
     if (key == 10) {

@@ -135,7 +135,7 @@ def test_c_abi_argument_checks():
 
 
 def _reset_tuning(lib):
-    for key, val in ((0, 0), (5, 0), (1, 1), (3, 0), (2, 0), (12, 1), (11, 248), (13, 248), (14, 1024), (8, 2000)):
+    for key, val in ((0, 0), (5, 0), (1, 1), (3, 0), (2, 0), (12, 1), (11, 248), (13, 248), (14, 1024), (8, 2000), (15, 600)):
         lib.lcgp_set_tuning(key, val)
 
 
@@ -151,7 +151,7 @@ def test_tuning_knobs_do_not_change_results():
     try:
         for settings in (((0, 2),), ((0, 8),), ((5, 8),), ((1, 2),), ((3, 1),), ((12, 0),), ((2, 4),),
                          ((12, 0), (2, 4)), ((11, 0), (13, 0)), ((11, 16), (13, 24)), ((0, 3),), ((0, 3), (12, 0)), ((14, 0),), ((14, 100000),),
-                         ((14, 100000), (2, 4)), ((14, 100000), (0, 2))):
+                         ((14, 100000), (2, 4)), ((14, 100000), (0, 2)), ((15, 0),), ((15, 100000), (6, 0))):
             for key, val in settings:
                 assert lib.lcgp_set_tuning(key, val) == 0
             v, g = m.loss_and_grad(u)

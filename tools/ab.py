@@ -14,7 +14,7 @@ import torch
 sys.path.insert(0, '.')
 from lcgp_amd import LCGP, synth, _hip  # noqa: E402
 
-DEFAULTS = {0: 0, 1: 1, 2: 0, 3: 0, 5: 0, 6: 4200, 7: 2048, 8: 2000, 9: 8, 10: 0, 11: 248, 12: 1, 13: 248, 14: 1024}
+DEFAULTS = {0: 0, 1: 1, 2: 0, 3: 0, 5: 0, 6: 4200, 7: 2048, 8: 2000, 9: 8, 10: 0, 11: 248, 12: 1, 13: 248, 14: 1024, 15: 600}
 
 
 def main():
