@@ -61,11 +61,11 @@ def stage_times(m, reps=3):
         _hip.check(lib.lcgp_kernel_build(sp, *args, C.c_void_p(eng.x.data_ptr()), C.c_void_p(0 if eng.sr is None else eng.sr.data_ptr()),
                                          C.c_void_p(eng.theta_dev.data_ptr()), ws), 'build')
         ev[1].record(st)
-        _hip.check(lib.lcgp_potrf_logdet(sp, *args, ws, None, None), 'potrf')
+        _hip.check(lib.lcgp_potrf_logdet(sp, *args, ws, None, None, None), 'potrf')
         ev[2].record(st)
-        _hip.check(lib.lcgp_trtri(sp, *args, ws), 'trtri')
+        _hip.check(lib.lcgp_trtri(sp, *args, ws, None), 'trtri')
         ev[3].record(st)
-        _hip.check(lib.lcgp_lauum(sp, *args, ws), 'lauum')
+        _hip.check(lib.lcgp_lauum(sp, *args, ws, None), 'lauum')
         ev[4].record(st)
         torch.cuda.synchronize(eng.device)
         for i, k in enumerate(names):
@@ -94,10 +94,11 @@ def host_cores():
     return cores
 
 
-def cpu_baseline(m, budget_s=40.0):
+def cpu_baseline(m, budget_s=12.0, repeats=3):
     """Reference algorithm (eigh form + autodiff) and Cholesky form for ONE component of the same workload on the
-    host cores.  Bounded: a probe at n=1024 picks the largest prefix of the training set (n, n/2, n/4 ...) whose
-    predicted eigh-form time fits the budget; a shorter prefix is scaled by (n/n_s)^3 and reported as such."""
+    host cores: median of `repeats` samples each, after one warm-up probe.  Bounded: the probe at n=1024 picks the
+    largest prefix of the training set (n, n/2, n/4 ...) whose predicted eigh-form time fits `budget_s` per sample; a
+    shorter prefix is scaled by (n/n_s)^3 and reported as such."""
     from oracle import cpu_baseline as cb
     from threadpoolctl import threadpool_limits
     cores = host_cores()
@@ -106,19 +107,26 @@ def cpu_baseline(m, budget_s=40.0):
     xs, ys = m.x.numpy(), m.y.numpy()
     n, q, k = int(m.n), int(m.q), 0
 
-    def run(ns):
+    def eigh(ns):
         with threadpool_limits(limits=cores):
-            a = cb.eigh_form_component(xs[:ns], ys[:, :ns], phi[:, k], D[k], lLmb[k], lLmb0[k], lnug[k], ls2b, threads=cores)
-            b = cb.chol_form_component(xs[:ns], ys[:, :ns], phi[:, k], D[k], lLmb[k], lLmb0[k], lnug[k], ls2b)
-        return a, b
+            return cb.eigh_form_component(xs[:ns], ys[:, :ns], phi[:, k], D[k], lLmb[k], lLmb0[k], lnug[k], ls2b, threads=cores)
+
+    def chol(ns):
+        with threadpool_limits(limits=cores):
+            return cb.chol_form_component(xs[:ns], ys[:, :ns], phi[:, k], D[k], lLmb[k], lLmb0[k], lnug[k], ls2b, threads=cores)
     probe_n = min(n, 1024)
-    (t_probe, _, _), _ = run(probe_n)
+    t_probe = eigh(probe_n)[0]                     # also the warm-up (thread pools, MKL initialisation)
+    chol(probe_n)
     log('cpu probe: eigh-form component at n=%d took %.2f s on %d threads' % (probe_n, t_probe, cores))
     ns = n
     while ns > probe_n and t_probe * (ns / probe_n) ** 3 > budget_s:
         ns //= 2
-    (t_eigh, v_eigh, g_eigh), (t_chol, pieces) = run(ns)
-    log('cpu sample: n_s=%d eigh-form %.2f s, chol-form %.2f s' % (ns, t_eigh, t_chol))
+    t_eighs = [eigh(ns)[0] for _ in range(repeats)]
+    chols = [chol(ns) for _ in range(repeats)]
+    t_chols = [c[0] for c in chols]
+    pieces = chols[-1][1]
+    t_eigh, t_chol = float(np.median(t_eighs)), float(np.median(t_chols))
+    log('cpu samples: n_s=%d eigh-form %s s, chol-form %s s' % (ns, ['%.2f' % t for t in t_eighs], ['%.2f' % t for t in t_chols]))
     scale = (n / ns) ** 3
     model = ''
     try:
@@ -128,12 +136,14 @@ def cpu_baseline(m, budget_s=40.0):
                 break
     except Exception:
         pass
-    sample = '1 of %d components, first %d of %d inputs (eigh-form NLL + autodiff gradient, torch CPU fp64, %.1f s)' \
-             % (q, ns, n, t_eigh)
+    sample = ('median of %d timings of 1 of %d components, first %d of %d inputs (eigh-form NLL + autodiff gradient, torch CPU '
+              'fp64, %d threads, %.1f s each)' % (repeats, q, ns, n, cores, t_eigh))
     sample += ', scaled by q' + ('' if ns == n else ' and by (n/n_s)^3 = %g' % scale)
     base = dict(value=1.0 / (q * t_eigh * scale), unit='evals/s', cores=cores, kind='port', sample=sample,
-                cpu_model=model, n_sample=ns, eigh_form_s_per_component=t_eigh * scale,
-                chol_form_s_per_component=t_chol * scale, chol_form_evals_per_s=1.0 / (q * t_chol * scale))
+                cpu_model=model, n_sample=ns, repeats=repeats,
+                eigh_form_s_per_component=t_eigh * scale, eigh_form_samples_s=[t * scale for t in t_eighs],
+                chol_form_s_per_component=t_chol * scale, chol_form_samples_s=[t * scale for t in t_chols],
+                chol_form_evals_per_s=1.0 / (q * t_chol * scale))
     return base, pieces, ns
 
 
@@ -162,34 +172,6 @@ def main():
     assert world == args.gpus, 'launch with torch.distributed.run --nproc-per-node %d' % args.gpus
 
     from lcgp_amd import LCGP, synth, _hip
-    if os.environ.get('LCGP_OB'):
-        _hip.check(_hip.load().lcgp_set_tuning(0, int(os.environ['LCGP_OB'])), 'lcgp_set_tuning')
-    if os.environ.get('LCGP_SMALL'):
-        _hip.check(_hip.load().lcgp_set_tuning(6, int(os.environ['LCGP_SMALL'])), 'lcgp_set_tuning')
-    if os.environ.get('LCGP_STEP'):
-        _hip.check(_hip.load().lcgp_set_tuning(12, int(os.environ['LCGP_STEP'])), 'lcgp_set_tuning')
-    if os.environ.get('LCGP_FILL_STEP'):
-        _hip.check(_hip.load().lcgp_set_tuning(13, int(os.environ['LCGP_FILL_STEP'])), 'lcgp_set_tuning')
-    if os.environ.get('LCGP_FILL'):
-        _hip.check(_hip.load().lcgp_set_tuning(11, int(os.environ['LCGP_FILL'].split(',')[0])), 'lcgp_set_tuning')
-    if os.environ.get('LCGP_ANY'):
-        _hip.check(_hip.load().lcgp_set_tuning(10, int(os.environ['LCGP_ANY'])), 'lcgp_set_tuning')
-    if os.environ.get('LCGP_NW'):
-        _hip.check(_hip.load().lcgp_set_tuning(9, int(os.environ['LCGP_NW'])), 'lcgp_set_tuning')
-    if os.environ.get('LCGP_SMALL_SYRK'):
-        _hip.check(_hip.load().lcgp_set_tuning(8, int(os.environ['LCGP_SMALL_SYRK'])), 'lcgp_set_tuning')
-    if os.environ.get('LCGP_SMALL_LAUUM'):
-        _hip.check(_hip.load().lcgp_set_tuning(7, int(os.environ['LCGP_SMALL_LAUUM'])), 'lcgp_set_tuning')
-    if os.environ.get('LCGP_SB'):
-        _hip.check(_hip.load().lcgp_set_tuning(5, int(os.environ['LCGP_SB'])), 'lcgp_set_tuning')
-    if os.environ.get('LCGP_PRIO'):
-        _hip.check(_hip.load().lcgp_set_tuning(4, int(os.environ['LCGP_PRIO'])), 'lcgp_set_tuning')
-    if os.environ.get('LCGP_LA'):
-        _hip.check(_hip.load().lcgp_set_tuning(3, int(os.environ['LCGP_LA'])), 'lcgp_set_tuning')
-    if os.environ.get('LCGP_DBG'):
-        _hip.check(_hip.load().lcgp_set_tuning(2, int(os.environ['LCGP_DBG'])), 'lcgp_set_tuning')
-    if os.environ.get('LCGP_GROUPS'):
-        _hip.check(_hip.load().lcgp_set_tuning(1, int(os.environ['LCGP_GROUPS'])), 'lcgp_set_tuning')
     over = {} if args.n is None else dict(n=args.n)
     if args.q is not None:
         over['q'] = args.q
@@ -242,10 +224,13 @@ def main():
         out['stages_ms'] = st
         # dominant kernel: the single-launch LAUUM (tile_gemm<OP_LAUUM>): A^-1 = W^T W, n^3/3 flops per component
         fl = ql * float(n) ** 3 / 3.0
+        # HBM-side bytes of that launch come from separate rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; MI355X guide),
+        # summarised in profiles/traffic.json together with the source hash of the library they were measured on:
+        # a number measured on another build of the kernels is NOT reported
         traffic = None
         try:
             tj = json.load(open(os.path.join(ROOT, 'profiles', 'traffic.json')))
-            if world == 1 and args.config == 3 and args.n is None and args.q is None:   # measured for that launch only
+            if world == 1 and args.config == 3 and args.n is None and args.q is None and tj.get('lib_hash') == _hip.loaded_hash():
                 traffic = tj.get('tile_gemm_lauum_bytes_per_launch')
         except Exception:
             pass

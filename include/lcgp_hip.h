@@ -9,8 +9,11 @@
  *  - every pointer is a DEVICE pointer on the current device unless marked "host";
  *  - matrices are row-major;  `dtype`: 0 = float64, 1 = float32 (the reference is float64 only);
  *  - `stream` is a hipStream_t passed as void* (NULL = the null stream); every call only ENQUEUES
- *    work ordered after / before that stream and returns; no device memory is allocated, freed or
- *    synchronised inside (lcgp_nll_grad keeps a few internal streams and events, see lcgp_shutdown);
+ *    work on that stream and returns; no device memory is allocated, freed or synchronised inside
+ *    and no other stream or event is created;
+ *  - the library keeps NO mutable state (the only static is the thread-local text behind
+ *    lcgp_last_error): schedule parameters travel with the call (lcgp_sched), so calls on different
+ *    streams / devices / host threads are independent;
  *  - the caller owns all memory, including `workspace` (size from lcgp_workspace_bytes);
  *  - return value 0 = enqueued; < 0 = bad argument / HIP error (see lcgp_last_error()).
  *    A non positive-definite matrix is reported through the `info` word of the output block,
@@ -43,45 +46,40 @@ extern "C" {
 #define LCGP_F64 0
 #define LCGP_F32 1
 
-/* library version (major*10000 + minor*100 + patch) and last error text (host string). */
+/* library version (major*100 + minor), hash of the sources the binary was built from
+ * (sha256 of lcgp_hip.hip + lcgp_hip.h, first 16 hex digits; "unknown" if built without
+ * -DLCGP_SRC_HASH) and the last error text of the calling thread (host strings). */
 int lcgp_version(void);
+const char* lcgp_source_hash(void);
 const char* lcgp_last_error(void);
 
-/* width of the theta / output blocks described above. */
+/* width of the theta / output blocks described above, and of the reduced vector of lcgp_pack_partial. */
 int lcgp_theta_width(int d, int p);
 int lcgp_out_width(int d, int p);
+int lcgp_partial_width(int d, int p, int q_total);
 
-/* performance knobs (process-wide, for experiments; results do not depend on them beyond rounding):
- *   key 0: width of the outer Cholesky panel in 64-column blocks (default 0 = automatic: 4 in fp64, 8 in fp32);
- *   key 5: width of the Cholesky super-panel in 64-column blocks (default 0 = the panel width, i.e. off): trailing updates of the panels stop at
- *          the super-panel boundary, the rest of the matrix is updated once per super-panel;
- *   key 6 / key 7: below this many 128x128 tiles per launch (components x tiles) the triangular inverse (6, default
- *          4200) / A^-1 = W^T W (7, default 2048) run on 64x64 tiles: with few components a launch is bounded by
- *          its longest tile (0 = always 128x128);
- *   key 8: the same switch for the trailing update of the Cholesky (default 2000);
- *   key 11: filler blocks (128x64 tiles of the previous panel's trailing update) carried by each diagonal-block launch
- *          (default 248 = one per otherwise idle CU; 0 = no filler);
- *   key 12: 1 (default) = one launch per 64-column step of the Cholesky panel chain (panel TRMM with the previous
- *          column's update folded in, the next diagonal block factored by the workgroup of the tile above it);
- *          0 = diagonal block / panel TRMM / panel update as three dependent launches;
- *   key 13: filler blocks carried by each chain-step launch that ends in a diagonal block (default 248);
- *   key 14: a trailing-update launch of at most this many 64x64 tiles (x components) also factors the next panel's
- *          first diagonal block, so that panel's chain starts one launch earlier (default 1024; 0 = never);
- *   key 15: a level of the triangular inverse with fewer than this many 128x128 tiles (x components) runs on 64x64
- *          tiles even when the large levels use 128x128 ones (default 600);
- *   key 2: bit 2 (value 4) = barrier-per-pivot-pair variant of the diagonal-block kernel instead of the in-wave
- *          16-column panels (bits 0 and 1 skip work for timing experiments and give wrong results);
- *   key 3: 1 = look-ahead Cholesky (panel chain on an internal stream), 0 (default) = single stream;
- *   key 4: 1 = create that internal stream with the highest priority;
- *   key 1: number of component groups whose factorisation chains run on internal streams (default 1 = off, max 8). */
-int lcgp_set_tuning(int key, int value);
+/* Schedule of the factorisation / inverse (launch shapes only: results do not depend on it beyond
+ * rounding).  Passed per call as the last argument of the entry points that schedule launches;
+ * NULL = the defaults lcgp_sched_default() writes.  All counts are 64x64 or 128x128 tile counts
+ * TIMES the number of local components. */
+typedef struct lcgp_sched {
+    int outer_blocks;       /* width of the outer Cholesky panel in 64-column blocks; 0 = automatic (4 fp64, 8 fp32) */
+    int syrk_small_tiles;   /* a trailing update with fewer 128x128 tiles than this runs on 64x64 tiles (2000) */
+    int trtri_small_tiles;  /* the whole triangular inverse runs on 64x64 tiles below this many 128x128 tiles (4200) */
+    int lauum_small_tiles;  /* the same for A^-1 = W^T W (2048) */
+    int trtri_level_small;  /* a single level of the triangular inverse below this many 128x128 tiles: 64x64 tiles (600) */
+    int fill_leaf;          /* filler blocks (128x64 tiles of the previous panel's trailing update) carried by a
+                               diagonal-block launch (248 = one per otherwise idle CU; 0 = none) */
+    int fill_step;          /* filler blocks carried by a chain-step launch that ends in a diagonal block (248) */
+    int leaf_in_wide;       /* a trailing update of at most this many 64x64 tiles also factors the next panel's first
+                               diagonal block, so that panel's chain starts one launch earlier (1024; 0 = never) */
+} lcgp_sched;
+int lcgp_sched_default(lcgp_sched* sched /*host out*/);
 
-/* lcgp_nll_grad overlaps the dependent launch chains of different components on a few internal HIP streams
- * (created on first use, one set per device, kept for the life of the process).  lcgp_shutdown destroys them. */
-int lcgp_shutdown(void);
-
-/* bytes of `workspace` needed by lcgp_nll_grad / lcgp_potrf_logdet / lcgp_potri for q_local components. */
+/* bytes of `workspace` needed by lcgp_nll_grad / lcgp_potrf_logdet / lcgp_potri for q_local components,
+ * and of the `scratch` of lcgp_predict for n0 new inputs. */
 int lcgp_workspace_bytes(int dtype, int n, int d, int p, int q_local, size_t* bytes /*host out*/);
+int lcgp_predict_scratch_bytes(int dtype, int n, int q_local, int n0, size_t* bytes /*host out*/);
 
 /* Matern32(x1, x2, llmb, llmb0, lnug)  -- covmat.py:5-55 (build branch 31-55).
  * out (n1 x n2, row-major).  `same` != 0 adds the nugget term on the diagonal (the reference adds it
@@ -98,20 +96,21 @@ int lcgp_kernel_build(void* stream, int dtype, int n, int d, int p, int q_local,
                       const double* theta, void* workspace);
 
 /* K2: blocked Cholesky A_k = L_k L_k^T of the matrices left by lcgp_kernel_build, in place, plus
- * W = L^-1 blocks needed later.  Replaces tf.linalg.eigh (lcgp.py:652) / tf.linalg.cholesky
- * (lcgp.py:617) and the log-determinant (lcgp.py:660 / 624).
- * half_logdet (q_local doubles) and info (q_local ints) are written on the device. */
+ * the inverses of the 64x64 diagonal blocks needed later.  Replaces tf.linalg.eigh (lcgp.py:652) /
+ * tf.linalg.cholesky (lcgp.py:617) and the log-determinant (lcgp.py:660 / 624).
+ * half_logdet (q_local doubles) and info (q_local ints) are written on the device (either may be NULL). */
 int lcgp_potrf_logdet(void* stream, int dtype, int n, int d, int p, int q_local, void* workspace,
-                      double* half_logdet, int* info);
+                      double* half_logdet, int* info, const lcgp_sched* sched /*host or NULL*/);
 
 /* K4: A_k^-1 (lower tiles) from the factor left by lcgp_potrf_logdet.  Replaces the dense
  * U diag(.) U^T products of lcgp.py:654 / 705-715 and cholesky_solve with identity (lcgp.py:785). */
-int lcgp_potri(void* stream, int dtype, int n, int d, int p, int q_local, void* workspace);
+int lcgp_potri(void* stream, int dtype, int n, int d, int p, int q_local, void* workspace,
+               const lcgp_sched* sched);
 
 /* the two stages of lcgp_potri on their own (for per-kernel timing): W = L^-1 (level-parallel triangular
  * products), then A^-1 = W^T W (a single launch of the MFMA tile kernel; n^3/3 flops per component). */
-int lcgp_trtri(void* stream, int dtype, int n, int d, int p, int q_local, void* workspace);
-int lcgp_lauum(void* stream, int dtype, int n, int d, int p, int q_local, void* workspace);
+int lcgp_trtri(void* stream, int dtype, int n, int d, int p, int q_local, void* workspace, const lcgp_sched* sched);
+int lcgp_lauum(void* stream, int dtype, int n, int d, int p, int q_local, void* workspace, const lcgp_sched* sched);
 
 /* copies matrix `which` (0 = A/L, 1 = L^-1, 2 = A^-1) of local component k out of the workspace as a
  * dense n x n row-major matrix (lower triangle valid, upper triangle mirrored); for tests. */
@@ -132,15 +131,26 @@ int lcgp_fetch_vector(void* stream, int dtype, int n, int d, int p, int q_local,
  *   theta, out : device blocks described at the top (q_local rows each) */
 int lcgp_nll_grad(void* stream, int dtype, int n, int d, int p, int q_local,
                   const void* x, const void* Y, const void* sr,
-                  const double* theta, void* workspace, double* out);
+                  const double* theta, void* workspace, double* out, const lcgp_sched* sched);
+
+/* Assembles this rank's share of the vector the ranks all-reduce (in the reference the sum over
+ * k of lcgp.py:650-661 and the gradient tape's accumulation), on the device, in a fixed summation order:
+ *   vec = [ sum_k (half_logdet_k - quad_k/(2 D_k)) | sum_k info_k | g_ell (q_total x d) | g_scale (q_total) |
+ *           g_nug (q_total) | g_sigma (p) ]                          width lcgp_partial_width(d, p, q_total)
+ * with g_sigma_a = sum_k psi_k[a] gsig_k[a] / (2 D_k) over the LOCAL components; the slots of component i of
+ * this rank are written at its global index comp[i] (device ints), all other slots are zeroed.  q_local may
+ * be 0 (a rank without components contributes zeros). */
+int lcgp_pack_partial(void* stream, int d, int p, int q_local, int q_total, const int* comp,
+                      const double* theta, const double* out, double* vec);
 
 /* K6 prediction (lcgp.py:808-859 / 864-930 with the caches of 685-803): for local component k and
  * n0 new inputs x0 (already standardised) computes
  *     ghat[k, :] = c0k (sr o z_k)                       (lcgp.py:831 / 888)
  *     gvar[k, :] = scale_k - D_k rowsum((c0k o sr) A_k^-1 (c0k o sr)^T)   (lcgp.py:832 / 891-894)
- * using A_k^-1 and z_k left in the workspace by the last lcgp_nll_grad call with the same theta.
- * `same` as in lcgp_matern32 (nugget on the diagonal when x0 is the training set itself).
- * scratch: 2 * n0pad * npad elements of dtype (n0pad = n0 rounded up to 64, npad = n rounded up to 128). */
+ * using L_k^-1 and z_k left in the workspace by the last lcgp_nll_grad call with the same theta.
+ * `same`: 0 = x0 is not the training set; s >= 1 = row i of x0 IS training input i + s - 1 (x0 is the training set or a
+ * contiguous chunk of it starting at row s - 1), so the nugget term goes to that entry (covmat.py:46-51).
+ * scratch: lcgp_predict_scratch_bytes(dtype, n, q_local, n0) bytes. */
 int lcgp_predict(void* stream, int dtype, int n, int d, int p, int q_local,
                  const void* x, const void* sr, const double* theta, const void* workspace,
                  int n0, const void* x0, int same, void* scratch,

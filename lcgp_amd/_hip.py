@@ -17,43 +17,75 @@ HDR_PATH = os.path.join(_ROOT, "include", "lcgp_hip.h")
 
 F64, F32 = 0, 1
 
+
+class Sched(C.Structure):
+    """lcgp_sched of include/lcgp_hip.h: launch shapes of the factorisation / inverse, passed per call."""
+    _fields_ = [("outer_blocks", C.c_int), ("syrk_small_tiles", C.c_int), ("trtri_small_tiles", C.c_int),
+                ("lauum_small_tiles", C.c_int), ("trtri_level_small", C.c_int), ("fill_leaf", C.c_int),
+                ("fill_step", C.c_int), ("leaf_in_wide", C.c_int)]
+
+
 # every symbol include/lcgp_hip.h declares: name -> (restype, argtypes)
 _vp, _i, _d = C.c_void_p, C.c_int, C.c_double
+_sp = C.POINTER(Sched)
 SIGNATURES = {
     "lcgp_version": (_i, []),
+    "lcgp_source_hash": (C.c_char_p, []),
     "lcgp_last_error": (C.c_char_p, []),
     "lcgp_theta_width": (_i, [_i, _i]),
     "lcgp_out_width": (_i, [_i, _i]),
-    "lcgp_set_tuning": (_i, [_i, _i]),
-    "lcgp_shutdown": (_i, []),
+    "lcgp_partial_width": (_i, [_i, _i, _i]),
+    "lcgp_sched_default": (_i, [_sp]),
     "lcgp_workspace_bytes": (_i, [_i, _i, _i, _i, _i, C.POINTER(C.c_size_t)]),
+    "lcgp_predict_scratch_bytes": (_i, [_i, _i, _i, _i, C.POINTER(C.c_size_t)]),
     "lcgp_matern32": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, C.POINTER(_d), _d, _d, _i, _vp]),
     "lcgp_kernel_build": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
-    "lcgp_potrf_logdet": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
-    "lcgp_potri": (_i, [_vp, _i, _i, _i, _i, _i, _vp]),
-    "lcgp_trtri": (_i, [_vp, _i, _i, _i, _i, _i, _vp]),
-    "lcgp_lauum": (_i, [_vp, _i, _i, _i, _i, _i, _vp]),
+    "lcgp_potrf_logdet": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _sp]),
+    "lcgp_potri": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _sp]),
+    "lcgp_trtri": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _sp]),
+    "lcgp_lauum": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _sp]),
     "lcgp_fetch_matrix": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _i, _i, _vp]),
     "lcgp_fetch_vector": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _i, _i, _vp]),
-    "lcgp_nll_grad": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "lcgp_nll_grad": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _sp]),
+    "lcgp_pack_partial": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "lcgp_predict": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp, _i, _vp, _vp, _vp]),
 }
 
 _lib = None
 
 
-def needs_build() -> bool:
+def source_hash() -> str:
+    """sha256 over the sources the library is built from (first 16 hex digits); compiled into the binary as
+    LCGP_SRC_HASH and returned by lcgp_source_hash(), so source and binary can be compared on any box."""
+    import hashlib
+    h = hashlib.sha256()
+    for path in (SRC_PATH, HDR_PATH):
+        with open(path, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
+def binary_hash():
+    """LCGP_SRC_HASH of the shared object on disk (read from the file, the library is not loaded), or None."""
+    import re
     if not os.path.exists(LIB_PATH):
-        return True
-    t = os.path.getmtime(LIB_PATH)
-    return any(os.path.exists(s) and os.path.getmtime(s) > t for s in (SRC_PATH, HDR_PATH))
+        return None
+    with open(LIB_PATH, "rb") as f:
+        m = re.search(rb"LCGP_SRC_HASH=([0-9a-f]{16})", f.read())
+    return m.group(1).decode() if m else None
+
+
+def needs_build() -> bool:
+    return binary_hash() != source_hash()
 
 
 def build_library(force: bool = False, verbose: bool = False) -> str:
-    """hipcc --offload-arch=gfx950 -> lcgp_amd/liblcgp_hip.so (cross-compiles without a GPU)."""
+    """hipcc --offload-arch=gfx950 -> lcgp_amd/liblcgp_hip.so (cross-compiles without a GPU).  Rebuilds whenever the
+    hash embedded in the binary differs from the hash of the sources (not an mtime test)."""
     if not force and not needs_build():
         return LIB_PATH
-    cmd = ["hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-shared", "-o", LIB_PATH, SRC_PATH]
+    cmd = ["hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-shared",
+           '-DLCGP_SRC_HASH="LCGP_SRC_HASH=%s"' % source_hash(), "-o", LIB_PATH, SRC_PATH]
     res = subprocess.run(cmd, capture_output=True, text=True)
     if verbose or res.returncode != 0:
         print(" ".join(cmd))
@@ -81,6 +113,17 @@ def load():
         fn.argtypes = args
     _lib = lib
     return lib
+
+
+def loaded_hash() -> str:
+    """The source hash the LOADED library reports."""
+    return load().lcgp_source_hash().decode().split("=")[-1]
+
+
+def default_sched() -> Sched:
+    s = Sched()
+    check(load().lcgp_sched_default(C.byref(s)), "lcgp_sched_default")
+    return s
 
 
 def check(rc: int, what: str):

@@ -12,7 +12,6 @@
 // the padding is the identity so every kernel works on whole 64x64 tiles):
 //   M : A, then L (lower tiles)      W : L^-1 (lower tiles)      V : scratch, then A^-1 (lower tiles)
 #include <hip/hip_runtime.h>
-#include <hip/hip_ext.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <string.h>
@@ -20,7 +19,7 @@
 
 #include "../../include/lcgp_hip.h"
 
-#define LCGP_VERSION 100
+#define LCGP_VERSION 200
 
 namespace {
 
@@ -263,7 +262,7 @@ __global__ __launch_bounds__(256) void cross_kernel(T* __restrict__ out, int ldo
                 ssum -= s;
             }
             double c0 = poly * exp(ssum);
-            double dl = (same && gi == gj) ? 1.0 : 0.0;
+            double dl = (same && gi + (same - 1) == gj) ? 1.0 : 0.0;   // same = 1 + row offset of x1 within x2
             v = scale * ((1.0 - nt) * c0 + nt * dl) * cs[j];
         }
         out[(size_t)gi * ldo + gj] = (T)v;
@@ -286,65 +285,7 @@ __device__ __forceinline__ double fast_rcp(double a) {
     return x;
 }
 
-// (measured alternatives, all slower on MI355X: fully unrolled step loop 38-41 us per block; pivot column broadcast
-// with v_readlane instead of LDS 36 us; owner lanes publishing 1/pivot at the end of the previous step 36 us; one
-// pivot per barrier 27 us.)
-// 16 pivot steps [s0, s0 + 16) of the in-register Cholesky, TWO pivots per barrier.  Rows rg + 4m with m < M0 lie
-// above the pivots of this group and are skipped statically; the step loop is rolled on purpose (a fully unrolled
-// chain runs at instruction-fetch speed).  Per pair (s, s+1) the owner lanes publish both columns as they stand
-// (column s+1 NOT yet updated by pivot s), permuted so that the 16 entries a wave needs (rows rg + 4m) are
-// contiguous: row i sits at (i & 3) * 16 + (i >> 2).  Every thread then factors the 2x2 pivot block itself
-// (l = a/c_ss, b' = b - a l) and applies the rank-2 update  a_ij -= c_i (c_j/c_ss) + c'_i (c'_j/b')  with
-// c' = c_{.,s+1} - c_{.,s} l:  one barrier and one LDS round trip per two pivots.
-template <int M0>
-__device__ __forceinline__ void leaf_pivot_group(double (&r)[16], double (*colbuf)[2][TS], int s0, int cj, int rg,
-                                                 double& piv, int& first_bad, int jb) {
-#pragma unroll 1
-    for (int s = s0; s < s0 + 16; s += 2) {
-        double* cb0 = colbuf[(s >> 1) & 1][0];
-        double* cb1 = colbuf[(s >> 1) & 1][1];
-        if (cj == s) {
-#pragma unroll
-            for (int m = M0; m < 16; ++m) cb0[rg * 16 + m] = r[m];
-        }
-        if (cj == s + 1) {
-#pragma unroll
-            for (int m = M0; m < 16; ++m) cb1[rg * 16 + m] = r[m];
-        }
-        __syncthreads();
-        const int ps = ((s & 3) << 4) + (s >> 2), ps1 = (((s + 1) & 3) << 4) + ((s + 1) >> 2);
-        const int pc = ((cj & 3) << 4) + (cj >> 2);
-        const double css = cb0[ps], a10 = cb0[ps1], b11 = cb1[ps1];
-        const double ccj0 = cb0[pc], ccj1 = cb1[pc];
-        double c0[16], c1[16];
-#pragma unroll
-        for (int m = M0; m < 16; ++m) {       // wave-uniform addresses: LDS broadcasts
-            c0[m] = cb0[rg * 16 + m];
-            c1[m] = cb1[rg * 16 + m];
-        }
-        const double r1 = fast_rcp(css);
-        const double l10 = a10 * r1;
-        const double bp = fma(-a10, l10, b11);
-        const double r2 = fast_rcp(bp);
-        if (first_bad == 0) {
-            if (!(css > 0.0)) first_bad = jb * TS + s + 1;
-            else if (!(bp > 0.0)) first_bad = jb * TS + s + 2;
-        }
-        if (cj == s) piv = css;
-        if (cj == s + 1) piv = bp;
-        if (cj > s) {
-            const double t1 = ccj0 * r1;
-            const double t2 = cj > s + 1 ? fma(-ccj0, l10, ccj1) * r2 : 0.0;
-#pragma unroll
-            for (int m = M0; m < 16; ++m) {
-                const double c1p = fma(-c0[m], l10, c1[m]);
-                r[m] = fma(-c1p, t2, fma(-c0[m], t1, r[m]));
-            }
-        }
-    }
-}
-
-// ---- in-wave panel variant of the diagonal-block factorisation (default) ----
+// ---- in-wave panel factorisation of the diagonal block ----
 // The 64x64 block is split into four 16-column panels, one per wave.  Wave w keeps block column w as fp64 MFMA
 // accumulators (lane (c = l & 15, g = l >> 4), reg e <-> row 16 rb + g + 4 e, column 16 w + c).  When its turn
 // comes it turns the panel into ROW layout through a private LDS scratch (lane = row, 16 registers = the panel's
@@ -436,33 +377,9 @@ __device__ __forceinline__ void leaf_factor_panels(const T* __restrict__ Mb, int
     }
 }
 
-// barrier-per-pivot-pair variant (tuning key 2, bit 4): the block in registers of all 256 threads
-__device__ __forceinline__ void leaf_factor_pairs(const double* __restrict__ unused, double (&r)[16], double (*lt)[LEAF_LDT],
-                                                  double* scratch, double* dinv, double* pivs, int* bad, int jb, int dbg) {
-    double (*colbuf)[2][TS] = (double (*)[2][TS])scratch;
-    const int tid = threadIdx.x, cj = tid & 63, rg = tid >> 6;
-    double piv = 1.0;
-    int first_bad = 0;
-    if (!(dbg & 1)) {
-        leaf_pivot_group<0>(r, colbuf, 0, cj, rg, piv, first_bad, jb);
-        leaf_pivot_group<4>(r, colbuf, 16, cj, rg, piv, first_bad, jb);
-        leaf_pivot_group<8>(r, colbuf, 32, cj, rg, piv, first_bad, jb);
-        leaf_pivot_group<12>(r, colbuf, 48, cj, rg, piv, first_bad, jb);
-    }
-    const double rs = 1.0 / sqrt(piv);      // column cj is final up to the scaling by 1/sqrt(pivot)
-#pragma unroll
-    for (int m = 0; m < 16; ++m) {
-        const int i = rg + 4 * m;
-        lt[cj][i] = i >= cj ? r[m] * rs : 0.0;
-    }
-    if (rg == 0) { dinv[cj] = rs; pivs[cj] = piv; }
-    if (tid < 4) bad[tid] = tid == 0 ? first_bad : 0;
-    __syncthreads();
-}
-
 template <typename T>
 __device__ __forceinline__ void leaf_body(unsigned char* lds, int k, T* __restrict__ M, T* __restrict__ W, size_t mat,
-                                          int npad, int jb, double* __restrict__ logdet, int* __restrict__ info, int dbg) {
+                                          int npad, int jb, double* __restrict__ logdet, int* __restrict__ info) {
     double (*lt)[LEAF_LDT] = (double (*)[LEAF_LDT])lds;                   // lt[col][row] = L[row][col]
     double* scratch = (double*)lds + TS * LEAF_LDT;
     double (*w)[LEAF_LDT] = (double (*)[LEAF_LDT])scratch;                // the inverse; overlays the factor's scratch
@@ -474,17 +391,7 @@ __device__ __forceinline__ void leaf_body(unsigned char* lds, int k, T* __restri
     T* Wb = W + (size_t)k * mat + (size_t)jb * TS * npad + (size_t)jb * TS;
     const int cj = tid & 63;
     const int rg = tid >> 6;
-    if (dbg & 4) {
-        double r[16];
-#pragma unroll
-        for (int m = 0; m < 16; ++m) {
-            const int i = rg + 4 * m;
-            r[m] = cj <= i ? (double)Mb[(size_t)i * npad + cj] : 0.0;
-        }
-        leaf_factor_pairs(nullptr, r, lt, scratch, dinv, pivs, bad, jb, dbg);
-    } else {
-        leaf_factor_panels<T>(Mb, npad, lt, scratch, dinv, pivs, bad, jb);
-    }
+    leaf_factor_panels<T>(Mb, npad, lt, scratch, dinv, pivs, bad, jb);
 #pragma unroll
     for (int m = 0; m < 16; ++m) {
         const int i = rg + 4 * m;
@@ -499,7 +406,6 @@ __device__ __forceinline__ void leaf_body(unsigned char* lds, int k, T* __restri
             if (fb && info[k] == 0) info[k] = fb;
         }
     }
-    if (dbg & 2) return;
     // ---- inverse of the 64x64 lower-triangular block, blocked by 16 ----
     // (a) the four 16x16 diagonal blocks: thread = one column, kept in registers (solve L w = e_cl)
     if (tid < TS) {
@@ -555,9 +461,9 @@ __device__ __forceinline__ void leaf_body(unsigned char* lds, int k, T* __restri
 
 template <typename T>
 __global__ __launch_bounds__(256) void leaf_kernel(T* __restrict__ M, T* __restrict__ W, size_t mat, int npad, int jb,
-                                                   double* __restrict__ logdet, int* __restrict__ info, int dbg) {
+                                                   double* __restrict__ logdet, int* __restrict__ info) {
     __shared__ __align__(16) unsigned char lds[LEAF_LDS_BYTES];
-    leaf_body<T>(lds, blockIdx.x, M, W, mat, npad, jb, logdet, info, dbg);
+    leaf_body<T>(lds, blockIdx.x, M, W, mat, npad, jb, logdet, info);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -567,7 +473,7 @@ __global__ __launch_bounds__(256) void leaf_kernel(T* __restrict__ M, T* __restr
 //   MK : element (m, k) at P[m * ld + k]      KM : element (m, k) at P[k * ld + m]
 // and staged in LDS as [k][m] (KT = 16 k rows per stage, double buffered through registers).
 // ---------------------------------------------------------------------------------------------------
-enum GemmOp { OP_TRMM_PANEL = 0, OP_SYRK = 1, OP_TRTRI_T = 2, OP_TRTRI_W = 3, OP_LAUUM = 4, OP_PRED_U = 5 };
+enum GemmOp { OP_SYRK = 1, OP_TRTRI_T = 2, OP_TRTRI_W = 3, OP_LAUUM = 4, OP_PRED_U = 5 };
 enum Lay { MK = 0, KM = 1 };
 
 struct GemmArgs {
@@ -659,14 +565,7 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, const int lin /*blo
     int nkt;
     double alpha = 1.0;
     bool accumulate = false;
-    if constexpr (OP == OP_TRMM_PANEL) {
-        // M[r, j] = M[r, j] * W[j, j]^T for r = j+1+bid      (L21 = A21 L11^-T)
-        const int j = g.p0, r = j + 1 + bid;
-        A0 = Ab + (size_t)r * TM * g.ldA + (size_t)j * TM; dA = 0;
-        B0 = Bb + (size_t)j * TM * g.ldB + (size_t)j * TM; dB = 0;
-        nkt = 1;
-        Ct = Cb + (size_t)r * TM * g.ldC + (size_t)j * TM;
-    } else if constexpr (OP == OP_SYRK) {
+    if constexpr (OP == OP_SYRK) {
         // M[r, c] -= sum_{kt in [p0, p1)} M[r, kt] M[c, kt]^T over the tiles c in [p2, p3), r in [c, nb)
         // (p3 == nb: the whole trailing triangle; p3 < nb: the rest of the current panel), column-major
         int t = bid + g.t0, c = g.p2;
@@ -770,8 +669,8 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, const int lin /*blo
     };
     bool done = false;
     if constexpr (TM == 64) {
-        // K = 64 (panel TRMM, rank-64 panel update): these launches are one or two rounds of tiles and their time
-        // is the latency of ONE tile -- fetch all four stages up front (one memory latency instead of four)
+        // K = 64: such a launch is one or two rounds of tiles and its time is the latency of ONE tile -- fetch all
+        // four stages up front (one memory latency instead of four)
         if (nkt == 1) {
             T pa[SPT][EPT], pb[SPT][EPT];
 #pragma unroll
@@ -793,7 +692,11 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, const int lin /*blo
         // register prefetch PF stages ahead (the loads of stage s+PF are issued while stage s is multiplied): with
         // few workgroups per CU one stage of MFMAs (~0.5 us) does not cover an HBM/L2 round trip; the 64-tile kernel,
         // whose launches are often a fraction of a round, looks a whole k tile ahead
-        constexpr int PF = (TM == 64 && OP != OP_SYRK) ? 4 : 2;   // (the rank-k update holds its C tile too: 4 would spill)
+        // Depth by register budget (128 VGPRs per lane at the occupancy the launches need): the fp64 rank-k update
+        // holds its C tile in the accumulators from the start, so it looks ONE stage ahead (an fp64 stage is ~1.7 us of
+        // MFMA work per workgroup: enough to cover an L2/HBM round trip with two workgroups per CU); deeper would spill.
+        constexpr bool F64 = sizeof(T) == 8;
+        constexpr int PF = (OP == OP_SYRK) ? (F64 ? 1 : 2) : (TM == 64 ? (F64 ? 2 : 4) : 2);
         T ra[PF][EPT], rb[PF][EPT];
 #pragma unroll
         for (int h = 0; h < PF; ++h) {
@@ -805,22 +708,22 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, const int lin /*blo
         }
         for (int s = 0; s < nst; s += PF) {
 #pragma unroll
-            for (int h = 0; h < PF; ++h) {       // (s + h) & 1 == h & 1: static register / buffer index
+            for (int h = 0; h < PF; ++h) {       // static register index h; LDS buffer (s + h) & 1
                 if (s + h < nst) {
-                    store_stage<T, LA, TM, NT>(As + (h & 1) * KT * LD, ra[h], tid);
-                    store_stage<T, LB, TM, NT>(Bs + (h & 1) * KT * LD, rb[h], tid);
+                    const int buf = (PF & 1) ? ((s + h) & 1) : (h & 1);
+                    store_stage<T, LA, TM, NT>(As + buf * KT * LD, ra[h], tid);
+                    store_stage<T, LB, TM, NT>(Bs + buf * KT * LD, rb[h], tid);
                     __syncthreads();
                     if (s + h + PF < nst) {
                         const int kt = (s + h + PF) / SPT, ks = ((s + h + PF) % SPT) * KT;
                         load_stage<T, LA, TM, NT>(A0 + (ptrdiff_t)kt * dA, g.ldA, ks, ra[h], tid);
                         load_stage<T, LB, TM, NT>(B0 + (ptrdiff_t)kt * dB, g.ldB, ks, rb[h], tid);
                     }
-                    compute_stage(h & 1);
+                    compute_stage(buf);
                 }
             }
         }
     }
-    // (the panel TRMM overwrites its own A tile: all of it went through LDS before the last barrier)
 #pragma unroll
     for (int mi = 0; mi < MIM; ++mi)
 #pragma unroll
@@ -940,10 +843,10 @@ __global__ __launch_bounds__(256, 2) void syrk_rect_kernel(GemmArgs g) {
 // exists inside such a launch; stream order between launches provides all the ordering.
 template <typename T>
 __global__ __launch_bounds__(256) void leaf_fill_kernel(T* __restrict__ M, T* __restrict__ W, size_t mat, int npad, int jb,
-                                                        double* __restrict__ logdet, int* __restrict__ info, int dbg,
+                                                        double* __restrict__ logdet, int* __restrict__ info,
                                                         int q, GemmArgs f) {
     __shared__ __align__(16) unsigned char lds[LEAF_LDS_BYTES];
-    if ((int)blockIdx.x < q) leaf_body<T>(lds, blockIdx.x, M, W, mat, npad, jb, logdet, info, dbg);
+    if ((int)blockIdx.x < q) leaf_body<T>(lds, blockIdx.x, M, W, mat, npad, jb, logdet, info);
     else syrk_rect_body<T>(f, blockIdx.x - q, lds);
 }
 
@@ -972,7 +875,7 @@ struct StepArgs {
     int has_special;     // tile (c+1, c) continues with the diagonal block c+1  (c + 1 < pe)
     int n_trmm;          // TRMM tiles per component INCLUDING the special one: rows c+1 .. nb-1
     int n_upd;           // delayed-update tiles per component
-    double* logdet; int* info; int dbg;
+    double* logdet; int* info;
     int nfill;           // filler blocks
     GemmArgs f;          // filler
 };
@@ -1090,7 +993,7 @@ __global__ __launch_bounds__(256) void chain_step_kernel(StepArgs a) {
             TL::store(acc, Dt, ld, lane, wm0, wn0);
             if (a.has_special && t == 0) {
                 __syncthreads();
-                leaf_body<T>(lds, k, (T*)a.M, (T*)a.W, a.mat, a.npad, c + 1, a.logdet, a.info, a.dbg);
+                leaf_body<T>(lds, k, (T*)a.M, (T*)a.W, a.mat, a.npad, c + 1, a.logdet, a.info);
             }
         }
         return;
@@ -1113,36 +1016,20 @@ __global__ __launch_bounds__(256) void chain_step_kernel(StepArgs a) {
     }
 }
 
-// Trailing update of a panel that also factors the FIRST diagonal block of the next panel: the first q workgroups
-// apply the panel to that 64x64 block themselves (K = panel width) and continue with leaf_body, the others are the
-// tiles of the wide update (tile 0 of the 128-tile form leaves that quadrant alone; the 64-tile form starts at tile 1).
-// The next panel's chain then starts with its first step launch -- one dependent launch less per panel, and the
-// diagonal block hides under the update.
+// Trailing update of a panel that also factors the FIRST diagonal block of the next panel: the first q workgroups run
+// leaf_body on that 64x64 block (the chain steps of the panel have already applied the panel to it: diag_end = pe + 1),
+// the others are the tiles of the wide update (tile 0 of the 128-tile form leaves that quadrant alone; the 64-tile form
+// starts at tile 1).  The next panel's chain then starts with its first step launch -- one dependent launch less per
+// panel, and the diagonal block hides under the update.
 template <typename T, int TM>
 __global__ __launch_bounds__(256, 2) void wide_leaf_kernel(GemmArgs g, T* __restrict__ M, T* __restrict__ W, size_t mat,
-                                                           int npad, int jb, int J, double* __restrict__ logdet,
-                                                           int* __restrict__ info, int dbg) {
+                                                           int npad, int jb, double* __restrict__ logdet,
+                                                           int* __restrict__ info) {
     constexpr int WIDE_LDS = 4 * KT * (TM + 16) * (int)sizeof(T);
     __shared__ __align__(16) unsigned char lds[WIDE_LDS > LEAF_LDS_BYTES ? WIDE_LDS : LEAF_LDS_BYTES];
     const int q = g.q;
     if ((int)blockIdx.x < q) {
-        typedef Tile64<T> TL;
-        const int k = blockIdx.x;
-        const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-        const int wm0 = (wave >> 1) * 32, wn0 = (wave & 1) * 32;
-        T* Mk = M + (size_t)k * mat;
-        T* Dt = Mk + (size_t)jb * TS * npad + (size_t)jb * TS;
-        if (J < jb) {     // the panel's contribution to the block has not been applied by the chain steps
-            typename TL::acc_t acc[2][2];
-            TL::load(acc, Dt, npad, lane, wm0, wn0);
-            for (int j = J; j < jb; ++j) {
-                const T* Lt = Mk + (size_t)jb * TS * npad + (size_t)j * TS;
-                TL::template mma<true>(acc, Lt, npad, Lt, npad, (T*)lds, tid, lane, wm0, wn0);
-            }
-            TL::store(acc, Dt, npad, lane, wm0, wn0);
-            __syncthreads();
-        }
-        leaf_body<T>(lds, k, M, W, mat, npad, jb, logdet, info, dbg);
+        leaf_body<T>(lds, blockIdx.x, M, W, mat, npad, jb, logdet, info);
         return;
     }
     gemm_body<T, OP_SYRK, TM, 4>(g, blockIdx.x - q, lds);
@@ -1418,8 +1305,6 @@ int do_build(hipStream_t st, const Ws& w, const void* x, const void* sr, const d
     return 0;
 }
 
-int g_waves128 = 8;       // experiment (lcgp_set_tuning key 9): 4 = 128x128 tiles with 4 waves x (4x4) accumulators
-
 template <typename T, int OP, int TM = TS>
 int launch_gemm(hipStream_t st, const GemmArgs& g, int ntiles, int q) {
     if (ntiles <= 0) return 0;
@@ -1428,73 +1313,35 @@ int launch_gemm(hipStream_t st, const GemmArgs& g, int ntiles, int q) {
     h.q = q;
     h.t0 = 0;
     h.skipq = 0;
-    if (TM == 128 && g_waves128 == 4) {
-        hipLaunchKernelGGL((tile_gemm<T, OP, TM, 4>), dim3((unsigned)ntiles * q), dim3(256), 0, st, h);
-        CHECK_LAUNCH("tile_gemm");
-        return 0;
-    }
     hipLaunchKernelGGL((tile_gemm<T, OP, TM, NW>), dim3((unsigned)ntiles * q), dim3(NW * 64), 0, st, h);
     CHECK_LAUNCH("tile_gemm");
     return 0;
 }
 
 // ---------------------------------------------------------------------------------------------------
-// Component groups on internal streams.  The Cholesky and the triangular inverse are chains of short,
-// dependent launches (64 diagonal blocks in sequence, shrinking trailing updates, small inverse levels): one
-// chain cannot fill 256 CUs.  The components are independent, so they are split into up to `g_groups` groups,
-// each chain on its own stream; the hardware overlaps the diagonal block of one group with the trailing updates
-// of another and fills the tail of one launch with the head of the next.  The big uniform launches (build,
-// A^-1 = W^T W, symv, gradient contraction) stay single launches over all components on the caller's stream.
-// Streams/events are created once per device and kept (lcgp_shutdown() releases them).
+// Schedule parameters.  They travel with each call (lcgp_sched in the header; NULL = lcgp_sched_default):
+// the library keeps no mutable state.  Results do not depend on them beyond rounding.
 // ---------------------------------------------------------------------------------------------------
-extern int g_chain_prio;
-constexpr int MAX_GROUPS = 8;
-int g_groups = 1;                       // lcgp_set_tuning key 1 (measured: > 2 groups run slower)
-struct StreamPool {
-    bool ready = false;
-    hipStream_t s[MAX_GROUPS];
-    hipEvent_t fork, join[MAX_GROUPS];
-    hipStream_t chain;                 // high-priority stream of the look-ahead Cholesky (panel chain)
-    hipEvent_t ev_panel, ev_next, ev_fork2, ev_join2;
-};
-StreamPool g_pool[16];
-
-int pool_get(StreamPool*& out) {
-    int dev = 0;
-    hipError_t e = hipGetDevice(&dev);
-    if (e != hipSuccess) return fail("hipGetDevice", e);
-    if (dev < 0 || dev >= 16) return bad("device index out of range");
-    StreamPool& p = g_pool[dev];
-    if (!p.ready) {
-        for (int i = 0; i < MAX_GROUPS; ++i) {
-            e = hipStreamCreateWithFlags(&p.s[i], hipStreamNonBlocking);
-            if (e != hipSuccess) return fail("hipStreamCreateWithFlags", e);
-            e = hipEventCreateWithFlags(&p.join[i], hipEventDisableTiming);
-            if (e != hipSuccess) return fail("hipEventCreateWithFlags", e);
-        }
-        e = hipEventCreateWithFlags(&p.fork, hipEventDisableTiming);
-        if (e != hipSuccess) return fail("hipEventCreateWithFlags", e);
-        int lo = 0, hi = 0;
-        (void)hipDeviceGetStreamPriorityRange(&lo, &hi);      // hi = numerically lowest = highest priority
-        e = hipStreamCreateWithPriority(&p.chain, hipStreamNonBlocking, g_chain_prio ? hi : lo);
-        if (e != hipSuccess) return fail("hipStreamCreateWithPriority", e);
-        hipEvent_t* evs[4] = {&p.ev_panel, &p.ev_next, &p.ev_fork2, &p.ev_join2};
-        for (int i = 0; i < 4; ++i) {
-            e = hipEventCreateWithFlags(evs[i], hipEventDisableTiming);
-            if (e != hipSuccess) return fail("hipEventCreateWithFlags", e);
-        }
-        p.ready = true;
-    }
-    out = &p;
-    return 0;
+inline lcgp_sched default_sched() {
+    lcgp_sched s;
+    s.outer_blocks = 0;            // 0 = automatic: 4 (fp64) / 8 (fp32) 64-blocks per outer Cholesky panel
+    s.syrk_small_tiles = 2000;     // below this many 128x128 tiles (x components) a trailing update runs on 64x64 tiles
+    s.trtri_small_tiles = 4200;    // the same switch for the whole triangular inverse ...
+    s.lauum_small_tiles = 2048;    // ... and for A^-1 = W^T W
+    s.trtri_level_small = 600;     // a single level of the triangular inverse below this many 128x128 tiles: 64x64 tiles
+    s.fill_leaf = 248;             // filler blocks (128x64 tiles) carried by a diagonal-block launch
+    s.fill_step = 248;             // ... and by a chain-step launch that ends in a diagonal block
+    s.leaf_in_wide = 1024;         // a trailing update of at most this many 64x64 tiles also factors the next diagonal block
+    return s;
 }
 
-int g_outer_blocks = 0;   // width of the outer Cholesky panel in 64-blocks (lcgp_set_tuning key 0); 0 = automatic: 4 in fp64,
-                          // 8 in fp32 (twice the MFMA rate per byte of read-modify-write traffic; measured at n = 4096 .. 16384)
-int g_super_blocks = 0;   // width of the Cholesky super-panel in 64-blocks (lcgp_set_tuning key 5); 0 = same as the panel
-                          // (measured: 8, 16, 32 are not faster at n=4096)
-int g_debug_mask = 0;     // lcgp_set_tuning key 2: 1 = skip pivots, 2 = skip inverse (timing experiments only, wrong results);
-                          // 4 = barrier-per-pivot-pair diagonal-block variant instead of the in-wave panels
+inline int check_sched(const lcgp_sched& s) {
+    if (s.outer_blocks < 0 || s.outer_blocks > 64) return bad("sched.outer_blocks must be in [0, 64]");
+    if (s.syrk_small_tiles < 0 || s.trtri_small_tiles < 0 || s.lauum_small_tiles < 0 || s.trtri_level_small < 0 ||
+        s.fill_leaf < 0 || s.fill_step < 0 || s.leaf_in_wide < 0)
+        return bad("sched fields must be >= 0");
+    return 0;
+}
 
 // 128 x 64 filler tiles over the 64-columns [c_lo, c_hi): column c has nb/2 - c/2 row blocks
 inline long rect_tiles(int nb, int c_lo, int c_hi) {
@@ -1507,27 +1354,10 @@ inline int trapezoid_tiles(int nb, int c_lo, int c_hi) {
     return (c_hi - c_lo) * nb - (c_lo + c_hi - 1) * (c_hi - c_lo) / 2;
 }
 
-// Two-level right-looking Cholesky.  Outer panels of `g_outer_blocks` 64-blocks: inside a panel every 64-column
-// step is  diagonal block -> panel TRMM -> rank-64 update of the REST OF THE PANEL only;  the trailing matrix
-// is touched once per outer panel with K = 64 * g_outer_blocks (read-modify-write traffic / g_outer_blocks).
-int g_chain_prio = 0;     // lcgp_set_tuning key 4: 1 = create the chain stream with the highest priority (before first use)
-int g_small_tiles_syrk = 2000;  // lcgp_set_tuning key 8
-int g_any_order = 0;      // lcgp_set_tuning key 10: launch the first diagonal block of a panel without the barrier bit
-int g_lookahead = 0;      // lcgp_set_tuning key 3: 1 = panel chain on its own stream ahead of the trailing update.
-                          // OFF by default: measured on MI355X / ROCm 7.2, as soon as one HIP stream waits on another
-                          // (barrier packet) every kernel boundary on the running stream costs 20-40 us, so the
-                          // overlapped schedule runs 2.2x SLOWER (potrf 6.6 -> 14.4 ms at n=4096, q=8); see DESIGN.md
-
-#define HIPCHECK(call, what)                                \
-    do {                                                    \
-        hipError_t e__ = (call);                            \
-        if (e__ != hipSuccess) return fail(what, e__);      \
-    } while (0)
-
-// Filler work carried by the diagonal-block launches: a range of 128x64 tiles of a trailing update (see leaf_fill_kernel).
+// Filler work carried by the chain launches: a range of 128x64 tiles of a trailing update (see leaf_fill_kernel).
 struct Filler {
-    GemmArgs f;          // OP_SYRK on 64-tiles; f.q set
-    long next = 0;       // next tile (trapezoid enumeration over columns [f.p2, f.p3))
+    GemmArgs f;          // f.q set
+    long next = 0;       // next tile (enumeration over the columns [f.p2, f.nb))
     long total = 0;
     bool active() const { return next < total; }
     // reserves up to `cap_blocks` blocks (= tiles x components); returns the block count and fills `out`
@@ -1542,79 +1372,42 @@ struct Filler {
     }
 };
 
-int g_step_fused = 1;    // lcgp_set_tuning key 12: 1 = one launch per 64-column step of the panel chain (chain_step_kernel),
-                          // 0 = diagonal block / panel TRMM / panel update as three launches
-int g_leaf_in_wide = 1024;// lcgp_set_tuning key 14: a trailing-update launch of at most this many 64x64 tiles also factors the next
-                          // panel's first diagonal block (0 = never)
-int g_fill_step = 248;    // filler blocks carried by a chain_step_kernel launch (lcgp_set_tuning key 13)
-int g_fill_leaf = 248;    // filler blocks (128x64 tiles) carried by a diagonal-block launch (lcgp_set_tuning key 11; 0 = off):
-                          // one per otherwise idle CU is nearly free (launch 26 -> 30 us), a second one costs what it would
-                          // cost in the wide launch
-
-// one outer panel [J, pe): per 64-column step  diagonal block -> panel TRMM -> rank-64 update of the rest of the panel;
-// every launch may carry filler tiles
+// One outer panel [J, pe) of the Cholesky: the diagonal block J on its own (unless the previous trailing-update
+// launch factored it), then ONE launch per 64-column step (chain_step_kernel); every launch may carry filler tiles.
 template <typename T>
-int potrf_panel(hipStream_t st, const Ws& w, int J, int pe, Filler* fill = nullptr, bool leaf_done = false,
-                bool next_leaf_in_wide = false) {
+int potrf_panel(hipStream_t st, const Ws& w, const lcgp_sched& sc, int J, int pe, Filler* fill, bool leaf_done,
+                bool next_leaf_in_wide) {
     T* M = (T*)(w.base + w.off_M);
     T* W = (T*)(w.base + w.off_W);
     double* logdet = (double*)(w.base + w.off_logdet);
     int* info = (int*)(w.base + w.off_info);
-    GemmArgs g, fa;
-    g.sA = g.sB = g.sC = w.mat; g.ldA = g.ldB = g.ldC = w.npad; g.nb = w.nb; g.q = w.q; g.t0 = 0;
-    if (g_step_fused) {
-        // diagonal block J on its own, then ONE launch per column (chain_step_kernel)
-        int nf = 0;
-        if (!leaf_done) {      // (otherwise the previous panel's trailing-update launch factored block J)
-            nf = fill ? fill->take(g_fill_leaf, fa) : 0;
-            if (nf > 0) {
-                hipLaunchKernelGGL((leaf_fill_kernel<T>), dim3(w.q + nf), dim3(256), 0, st, M, W, w.mat, w.npad, J, logdet,
-                                   info, g_debug_mask, w.q, fa);
-            } else {
-                hipLaunchKernelGGL((leaf_kernel<T>), dim3(w.q), dim3(256), 0, st, M, W, w.mat, w.npad, J, logdet, info,
-                                   g_debug_mask);
-            }
-            CHECK_LAUNCH("leaf_kernel");
-        }
-        for (int c = J; c < pe && c + 1 < w.nb; ++c) {
-            StepArgs a;
-            a.M = M; a.W = W; a.mat = w.mat; a.npad = w.npad; a.nb = w.nb;
-            a.c = c; a.J = J; a.pe = pe; a.q = w.q;
-            a.diag_end = pe + (next_leaf_in_wide ? 1 : 0);
-            a.has_special = c + 1 < pe ? 1 : 0;
-            a.n_trmm = w.nb - 1 - c;
-            a.n_upd = 0;
-            if (c > J && c + 1 < pe) a.n_upd = w.nb - (c + 1) - 1;     // the tiles below the diagonal of column c + 1
-            a.logdet = logdet; a.info = info; a.dbg = g_debug_mask;
-            nf = (fill && a.has_special) ? fill->take(g_fill_step, fa) : 0;
-            a.f = fa; a.nfill = nf;
-            const long nblk = (long)(a.n_trmm + a.n_upd) * w.q + nf;
-            hipLaunchKernelGGL((chain_step_kernel<T>), dim3((unsigned)nblk), dim3(256), 0, st, a);
-            CHECK_LAUNCH("chain_step_kernel");
-        }
-    } else
-    for (int c = J; c < pe; ++c) {
-        int nf = fill ? fill->take(g_fill_leaf, fa) : 0;
+    GemmArgs fa;
+    int nf = 0;
+    if (!leaf_done) {
+        nf = fill ? fill->take(sc.fill_leaf, fa) : 0;
         if (nf > 0) {
-            hipLaunchKernelGGL((leaf_fill_kernel<T>), dim3(w.q + nf), dim3(256), 0, st, M, W, w.mat, w.npad, c, logdet, info,
-                               g_debug_mask, w.q, fa);
-        } else if (c == J && J > 0 && g_any_order) {
-            hipExtLaunchKernelGGL((leaf_kernel<T>), dim3(w.q), dim3(256), 0, st, nullptr, nullptr, hipExtAnyOrderLaunch,
-                                  M, W, w.mat, w.npad, c, logdet, info, g_debug_mask);
+            hipLaunchKernelGGL((leaf_fill_kernel<T>), dim3(w.q + nf), dim3(256), 0, st, M, W, w.mat, w.npad, J, logdet, info,
+                               w.q, fa);
         } else {
-            hipLaunchKernelGGL((leaf_kernel<T>), dim3(w.q), dim3(256), 0, st, M, W, w.mat, w.npad, c, logdet, info,
-                               g_debug_mask);
+            hipLaunchKernelGGL((leaf_kernel<T>), dim3(w.q), dim3(256), 0, st, M, W, w.mat, w.npad, J, logdet, info);
         }
         CHECK_LAUNCH("leaf_kernel");
-        if (c + 1 >= w.nb) break;
-        g.A = M; g.B = W; g.C = M; g.p0 = c; g.p1 = g.p2 = g.p3 = 0;
-        int rc = launch_gemm<T, OP_TRMM_PANEL>(st, g, w.nb - 1 - c, w.q);
-        if (rc) return rc;
-        if (c + 1 < pe) {
-            g.A = M; g.B = M; g.C = M; g.p0 = c; g.p1 = c + 1; g.p2 = c + 1; g.p3 = pe;
-            rc = launch_gemm<T, OP_SYRK>(st, g, trapezoid_tiles(w.nb, c + 1, pe), w.q);
-            if (rc) return rc;
-        }
+    }
+    for (int c = J; c < pe && c + 1 < w.nb; ++c) {
+        StepArgs a;
+        a.M = M; a.W = W; a.mat = w.mat; a.npad = w.npad; a.nb = w.nb;
+        a.c = c; a.J = J; a.pe = pe; a.q = w.q;
+        a.diag_end = pe + (next_leaf_in_wide ? 1 : 0);
+        a.has_special = c + 1 < pe ? 1 : 0;
+        a.n_trmm = w.nb - 1 - c;
+        a.n_upd = 0;
+        if (c > J && c + 1 < pe) a.n_upd = w.nb - (c + 1) - 1;     // the tiles below the diagonal of column c + 1
+        a.logdet = logdet; a.info = info;
+        nf = (fill && a.has_special) ? fill->take(sc.fill_step, fa) : 0;
+        a.f = fa; a.nfill = nf;
+        const long nblk = (long)(a.n_trmm + a.n_upd) * w.q + nf;
+        hipLaunchKernelGGL((chain_step_kernel<T>), dim3((unsigned)nblk), dim3(256), 0, st, a);
+        CHECK_LAUNCH("chain_step_kernel");
     }
     // whatever the chain could not carry runs as one plain launch
     if (fill && fill->active()) {
@@ -1630,8 +1423,8 @@ int potrf_panel(hipStream_t st, const Ws& w, int J, int pe, Filler* fill = nullp
 
 // trailing update with the panel [J, pe) of the tile columns [c_lo, c_hi) (64-block units, all rows below)
 template <typename T>
-int potrf_trailing(hipStream_t st, const Ws& w, int J, int pe, int c_lo, int c_hi, bool tiles128, bool with_leaf = false,
-                   bool diag_preupdated = false) {
+int potrf_trailing(hipStream_t st, const Ws& w, const lcgp_sched& sc, int J, int pe, int c_lo, int c_hi, bool tiles128,
+                   bool with_leaf) {
     if (c_lo >= c_hi) return 0;
     T* M = (T*)(w.base + w.off_M);
     GemmArgs g;
@@ -1639,14 +1432,14 @@ int potrf_trailing(hipStream_t st, const Ws& w, int J, int pe, int c_lo, int c_h
     g.A = M; g.B = M; g.C = M;
     // 128x128 tiles when the panel boundaries are 128-aligned AND the launch has enough of them to fill the chip;
     // a launch with few tiles is bounded by the duration of one tile, which is 4x shorter on 64x64 tiles
-    if (tiles128 && (long long)w.q * trapezoid_tiles(w.nb / 2, c_lo / 2, c_hi / 2) >= g_small_tiles_syrk) {
+    if (tiles128 && (long long)w.q * trapezoid_tiles(w.nb / 2, c_lo / 2, c_hi / 2) >= sc.syrk_small_tiles) {
         g.nb = w.nb / 2; g.p0 = J / 2; g.p1 = pe / 2; g.p2 = c_lo / 2; g.p3 = c_hi / 2;
         const int nt = trapezoid_tiles(w.nb / 2, c_lo / 2, c_hi / 2);
         if (with_leaf) {
             g.q = w.q; g.t0 = 0; g.skipq = 1;
             hipLaunchKernelGGL((wide_leaf_kernel<T, 128>), dim3((unsigned)(nt + 1) * w.q), dim3(256), 0, st, g, M,
-                               (T*)(w.base + w.off_W), w.mat, w.npad, c_lo, diag_preupdated ? c_lo : J, (double*)(w.base + w.off_logdet),
-                               (int*)(w.base + w.off_info), g_debug_mask);
+                               (T*)(w.base + w.off_W), w.mat, w.npad, c_lo, (double*)(w.base + w.off_logdet),
+                               (int*)(w.base + w.off_info));
             CHECK_LAUNCH("wide_leaf_kernel");
             return 0;
         }
@@ -1655,179 +1448,93 @@ int potrf_trailing(hipStream_t st, const Ws& w, int J, int pe, int c_lo, int c_h
     g.nb = w.nb; g.p0 = J; g.p1 = pe; g.p2 = c_lo; g.p3 = c_hi;
     const int nt = trapezoid_tiles(w.nb, c_lo, c_hi);
     if (with_leaf) {
-        // tile 0 = the diagonal block itself: it belongs to the special workgroups
+        // tile 0 = the diagonal block itself: it belongs to the special workgroups (the chain steps of the panel have
+        // already applied the panel to it)
         g.q = w.q; g.t0 = 1; g.skipq = 0;
         hipLaunchKernelGGL((wide_leaf_kernel<T, 64>), dim3((unsigned)nt * w.q), dim3(256), 0, st, g, M,
-                           (T*)(w.base + w.off_W), w.mat, w.npad, c_lo, diag_preupdated ? c_lo : J, (double*)(w.base + w.off_logdet),
-                           (int*)(w.base + w.off_info), g_debug_mask);
+                           (T*)(w.base + w.off_W), w.mat, w.npad, c_lo, (double*)(w.base + w.off_logdet),
+                           (int*)(w.base + w.off_info));
         CHECK_LAUNCH("wide_leaf_kernel");
         return 0;
     }
     return launch_gemm<T, OP_SYRK>(st, g, nt, w.q);
 }
 
-// Two-level right-looking Cholesky with look-ahead.  Outer panels of `g_outer_blocks` 64-blocks; the trailing
-// matrix is touched once per outer panel with K = 64 * g_outer_blocks.  The panel factorisation is a chain of
-// short dependent launches that cannot fill the chip, the trailing update is wide: with look-ahead the panel
-// chain runs on a high-priority internal stream and only waits for the update of ITS OWN columns (the first
-// slice of the previous trailing update), so panel J+1 overlaps the rest of the trailing update of panel J.
+// Two-level right-looking Cholesky.  Outer panels of `ob` 64-blocks: inside a panel every 64-column step is ONE launch
+// (chain_step_kernel) that only touches the panel's block column and the rest of the panel; the trailing matrix is read
+// and written once per outer panel with K = 64 ob.  The trailing update of panel J is split by columns into one wide
+// launch (the columns of panel J+1 and as many more as do not fit below) and its right-most columns, which the chain
+// launches of panel J+1 carry as filler tiles -- the chain leaves >= 97 % of the CUs idle, and a second HIP stream
+// cannot fill them on this platform.
 template <typename T>
-int do_potrf(hipStream_t st, const Ws& w) {
+int do_potrf(hipStream_t st, const Ws& w, const lcgp_sched& sc) {
     double* logdet = (double*)(w.base + w.off_logdet);
     int* info = (int*)(w.base + w.off_info);
     hipLaunchKernelGGL(zero_stats_kernel, dim3((w.q + 63) / 64), dim3(64), 0, st, logdet, info, w.q);
     CHECK_LAUNCH("zero_stats");
-    const int ob = g_outer_blocks < 1 ? (sizeof(T) == 4 ? 8 : 4) : g_outer_blocks;
+    const int ob = sc.outer_blocks < 1 ? (sizeof(T) == 4 ? 8 : 4) : sc.outer_blocks;
     const bool t128 = (ob & 1) == 0;
-    if (!g_lookahead || w.nb <= ob) {
-        int sb = g_super_blocks < ob ? ob : g_super_blocks;
-        sb = sb / ob * ob;
-        if (sb == ob) {
-            // Two-level schedule with filler: the trailing update of panel J is split by columns into one wide
-            // 128x128-tile launch (the columns of panel J+1 and as many more as do not fit below) and the right-most
-            // columns, which the chain launches of panel J+1 carry as filler tiles (as many as those launches can
-            // hide: g_fill_leaf blocks each).
-            Filler fill;
-            bool leaf_done = false;
-            // filler capacity of a panel's chain launches, with and without a diagonal-block launch of its own
-            const int cap_with_leaf = g_step_fused ? g_fill_leaf + (ob - 1) * g_fill_step : ob * g_fill_leaf;
-            const int cap_no_leaf = (ob - 1) * g_fill_step;
-            for (int J = 0; J < w.nb; J += ob) {
-                const int pe = J + ob < w.nb ? J + ob : w.nb;
-                const int mid = pe + ob < w.nb ? pe + ob : w.nb;     // the next panel's own columns are never filler
-                auto first_filler_column = [&](int cap_blocks) {
-                    int c = w.nb;
-                    // filler rides on the chain launches of the NEXT panel [pe, mid): it must stay clear of that panel's
-                    // columns and, when those chain steps pre-apply the panel to the diagonal block (mid, mid) for a
-                    // trailing-update launch that factors it, of column `mid` too
-                    const int lo = mid + (g_step_fused && g_leaf_in_wide ? 2 : 0);
-                    if (t128 && cap_blocks >= w.q && lo < w.nb) {
-                        const long cap_tiles = cap_blocks / w.q;
-                        while (c - 2 >= lo && rect_tiles(w.nb, c - 2, w.nb) <= cap_tiles) c -= 2;
-                    }
-                    return c;
-                };
-                auto wide_on_small_tiles = [&](int c_hi) {
-                    return !(t128 && (long long)w.q * trapezoid_tiles(w.nb / 2, pe / 2, c_hi / 2) >= g_small_tiles_syrk);
-                };
-                // decided BEFORE the panel's chain, which then pre-applies the panel to the next diagonal block:
-                // When the update runs on 64x64 tiles (few tiles: late panels, few components) it also factors the next
-                // panel's first diagonal block (wide_leaf_kernel).  With many 128x128 tiles that does not pay: the
-                // diagonal-block launch carries filler of its own and the 8-wave tile kernel is the faster one.
-                int cf = w.nb;                                         // first filler column
-                bool next_leaf = false;
-                if (pe < w.nb) {
-                    cf = first_filler_column(cap_with_leaf);
-                    if (g_step_fused && g_leaf_in_wide && wide_on_small_tiles(cf)) {
-                        const int cf3 = first_filler_column(cap_no_leaf);
-                        // (that kernel holds two workgroups per CU, the plain 64-tile kernel four: launches of few rounds)
-                        if (wide_on_small_tiles(cf3) && (long long)w.q * trapezoid_tiles(w.nb, pe, cf3) <= g_leaf_in_wide) {
-                            next_leaf = true;
-                            cf = cf3;
-                        }
-                    }
-                }
-                int rc = potrf_panel<T>(st, w, J, pe, fill.active() ? &fill : nullptr, leaf_done, next_leaf);
-                if (rc) return rc;
-                if (pe >= w.nb) break;
-                rc = potrf_trailing<T>(st, w, J, pe, pe, cf, t128, next_leaf, next_leaf);   // one wide launch
-                if (rc) return rc;
-                leaf_done = next_leaf;
-                fill = Filler();
-                if (cf < w.nb) {                                                       // U2b
-                    GemmArgs& f = fill.f;
-                    f.A = w.base + w.off_M; f.B = f.A; f.C = (void*)f.A;
-                    f.sA = f.sB = f.sC = w.mat; f.ldA = f.ldB = f.ldC = w.npad; f.nb = w.nb;
-                    f.p0 = J; f.p1 = pe; f.p2 = cf; f.p3 = w.nb; f.q = w.q; f.t0 = 0;
-                    fill.total = rect_tiles(w.nb, cf, w.nb);
-                }
-            }
-            return 0;
-        }
-        // three levels: 64-column steps inside a panel of `ob` blocks, panels inside a super-panel of `sb` blocks
-        // (their trailing updates stop at the super-panel boundary, K = 64 ob), and one far update per super-panel
-        // with K = 64 sb (measured: not faster than two levels)
-        for (int S = 0; S < w.nb; S += sb) {
-            const int se = S + sb < w.nb ? S + sb : w.nb;
-            for (int J = S; J < se; J += ob) {
-                const int pe = J + ob < se ? J + ob : se;
-                int rc = potrf_panel<T>(st, w, J, pe);
-                if (rc) return rc;
-                rc = potrf_trailing<T>(st, w, J, pe, pe, se, t128);
-                if (rc) return rc;
-            }
-            int rc = potrf_trailing<T>(st, w, S, se, se, w.nb, t128);
-            if (rc) return rc;
-        }
-        return 0;
-    }
-    StreamPool* pool = nullptr;
-    int rc = pool_get(pool);
-    if (rc) return rc;
-    hipStream_t sc = pool->chain;
-    HIPCHECK(hipEventRecord(pool->ev_fork2, st), "hipEventRecord");
-    HIPCHECK(hipStreamWaitEvent(sc, pool->ev_fork2, 0), "hipStreamWaitEvent");
-    if (g_lookahead == 2) {        // experiment: the plain single-stream schedule, but on the internal stream
-        for (int J = 0; J < w.nb; J += ob) {
-            const int pe = J + ob < w.nb ? J + ob : w.nb;
-            rc = potrf_panel<T>(sc, w, J, pe);
-            if (rc) return rc;
-            rc = potrf_trailing<T>(sc, w, J, pe, pe, w.nb, t128);
-            if (rc) return rc;
-        }
-        HIPCHECK(hipEventRecord(pool->ev_join2, sc), "hipEventRecord");
-        HIPCHECK(hipStreamWaitEvent(st, pool->ev_join2, 0), "hipStreamWaitEvent");
-        return 0;
-    }
-    if (g_lookahead == 3) {        // experiment: chain on the caller's stream, trailing updates on the internal one
-        hipStream_t su = sc;
-        for (int J = 0; J < w.nb; J += ob) {
-            const int pe = J + ob < w.nb ? J + ob : w.nb;
-            if (J > 0) HIPCHECK(hipStreamWaitEvent(st, pool->ev_next, 0), "hipStreamWaitEvent");
-            rc = potrf_panel<T>(st, w, J, pe);
-            if (rc) return rc;
-            HIPCHECK(hipEventRecord(pool->ev_panel, st), "hipEventRecord");
-            if (pe < w.nb) {
-                HIPCHECK(hipStreamWaitEvent(su, pool->ev_panel, 0), "hipStreamWaitEvent");
-                const int mid = pe + ob < w.nb ? pe + ob : w.nb;
-                rc = potrf_trailing<T>(su, w, J, pe, pe, mid, t128);
-                if (rc) return rc;
-                HIPCHECK(hipEventRecord(pool->ev_next, su), "hipEventRecord");
-                rc = potrf_trailing<T>(su, w, J, pe, mid, w.nb, t128);
-                if (rc) return rc;
-            }
-        }
-        HIPCHECK(hipEventRecord(pool->ev_join2, su), "hipEventRecord");
-        HIPCHECK(hipStreamWaitEvent(st, pool->ev_join2, 0), "hipStreamWaitEvent");
-        return 0;
-    }
+    Filler fill;
+    bool leaf_done = false;
+    // filler capacity of a panel's chain launches, with and without a diagonal-block launch of its own
+    const int cap_with_leaf = sc.fill_leaf + (ob - 1) * sc.fill_step;
+    const int cap_no_leaf = (ob - 1) * sc.fill_step;
     for (int J = 0; J < w.nb; J += ob) {
         const int pe = J + ob < w.nb ? J + ob : w.nb;
-        if (J > 0) HIPCHECK(hipStreamWaitEvent(sc, pool->ev_next, 0), "hipStreamWaitEvent");
-        rc = potrf_panel<T>(sc, w, J, pe);
-        if (rc) return rc;
-        HIPCHECK(hipEventRecord(pool->ev_panel, sc), "hipEventRecord");
+        const int mid = pe + ob < w.nb ? pe + ob : w.nb;     // the next panel's own columns are never filler
+        auto first_filler_column = [&](int cap_blocks) {
+            int c = w.nb;
+            // filler rides on the chain launches of the NEXT panel [pe, mid): it must stay clear of that panel's
+            // columns and, when those chain steps pre-apply the panel to the diagonal block (mid, mid) for a
+            // trailing-update launch that factors it, of column `mid` too
+            const int lo = mid + (sc.leaf_in_wide ? 2 : 0);
+            if (t128 && cap_blocks >= w.q && lo < w.nb) {
+                const long cap_tiles = cap_blocks / w.q;
+                while (c - 2 >= lo && rect_tiles(w.nb, c - 2, w.nb) <= cap_tiles) c -= 2;
+            }
+            return c;
+        };
+        auto wide_on_small_tiles = [&](int c_hi) {
+            return !(t128 && (long long)w.q * trapezoid_tiles(w.nb / 2, pe / 2, c_hi / 2) >= sc.syrk_small_tiles);
+        };
+        // decided BEFORE the panel's chain, which then pre-applies the panel to the next diagonal block:
+        // when the update runs on 64x64 tiles (few tiles: late panels, few components) it also factors the next
+        // panel's first diagonal block (wide_leaf_kernel).  With many 128x128 tiles that does not pay: the
+        // diagonal-block launch carries filler of its own and the 8-wave tile kernel is the faster one.
+        int cf = w.nb;                                         // first filler column
+        bool next_leaf = false;
         if (pe < w.nb) {
-            HIPCHECK(hipStreamWaitEvent(st, pool->ev_panel, 0), "hipStreamWaitEvent");
-            const int mid = pe + ob < w.nb ? pe + ob : w.nb;          // columns of the NEXT panel first
-            rc = potrf_trailing<T>(st, w, J, pe, pe, mid, t128);
-            if (rc) return rc;
-            HIPCHECK(hipEventRecord(pool->ev_next, st), "hipEventRecord");
-            rc = potrf_trailing<T>(st, w, J, pe, mid, w.nb, t128);
-            if (rc) return rc;
+            cf = first_filler_column(cap_with_leaf);
+            if (sc.leaf_in_wide && wide_on_small_tiles(cf)) {
+                const int cf3 = first_filler_column(cap_no_leaf);
+                // (that kernel holds two workgroups per CU, the plain 64-tile kernel four: launches of few rounds)
+                if (wide_on_small_tiles(cf3) && (long long)w.q * trapezoid_tiles(w.nb, pe, cf3) <= sc.leaf_in_wide) {
+                    next_leaf = true;
+                    cf = cf3;
+                }
+            }
+        }
+        int rc = potrf_panel<T>(st, w, sc, J, pe, fill.active() ? &fill : nullptr, leaf_done, next_leaf);
+        if (rc) return rc;
+        if (pe >= w.nb) break;
+        rc = potrf_trailing<T>(st, w, sc, J, pe, pe, cf, t128, next_leaf);   // one wide launch
+        if (rc) return rc;
+        leaf_done = next_leaf;
+        fill = Filler();
+        if (cf < w.nb) {
+            GemmArgs& f = fill.f;
+            f.A = w.base + w.off_M; f.B = f.A; f.C = (void*)f.A;
+            f.sA = f.sB = f.sC = w.mat; f.ldA = f.ldB = f.ldC = w.npad; f.nb = w.nb;
+            f.p0 = J; f.p1 = pe; f.p2 = cf; f.p3 = w.nb; f.q = w.q; f.t0 = 0; f.skipq = 0;
+            fill.total = rect_tiles(w.nb, cf, w.nb);
         }
     }
-    HIPCHECK(hipEventRecord(pool->ev_join2, sc), "hipEventRecord");
-    HIPCHECK(hipStreamWaitEvent(st, pool->ev_join2, 0), "hipStreamWaitEvent");
     return 0;
 }
 
 // With few components in flight the 128x128 launches of the inverse are bounded by their LONGEST tile (one tile with
-// K = 4096 keeps a CU busy for ~0.5 ms while the rest of the chip idles): below `g_small_tiles` 128-tiles per
-// launch the same products run on 64x64 tiles (4x more, 4x shorter tiles).  lcgp_set_tuning key 6.
-int g_small_tiles_trtri = 4200;   // measured at n=4096: 64-tiles win for q_local <= 4, lose at 8
-int g_small_tiles_lauum = 2048;   //                      64-tiles win for q_local <= 3
-
+// K = 4096 keeps a CU busy for ~0.5 ms while the rest of the chip idles): below a threshold of 128-tiles per launch
+// the same products run on 64x64 tiles (4x more, 4x shorter tiles).
 inline bool use_small_tiles(const Ws& w, int threshold) {
     const int nb2 = w.nb / 2;
     return (long long)w.q * (nb2 * (nb2 + 1) / 2) < threshold;
@@ -1848,12 +1555,9 @@ int trtri_level(hipStream_t st, const Ws& w, int mb) {      // one level: pairs 
     return launch_gemm<T, OP_TRTRI_W, TM>(st, g, pairs * mb * mb, w.q);
 }
 
-int g_trtri_level_small = 600;  // lcgp_set_tuning key 15: a level with fewer 128x128 tiles (x components) than this runs on 64x64
-                               // tiles even when the large levels use 128x128 ones
-
 template <typename T>
-int do_trtri(hipStream_t st, const Ws& w) {
-    const bool all_small = use_small_tiles(w, g_small_tiles_trtri);
+int do_trtri(hipStream_t st, const Ws& w, const lcgp_sched& sc) {
+    const bool all_small = use_small_tiles(w, sc.trtri_small_tiles);
     // levels in 64-block units: mb64 = 1 joins pairs of 64-blocks (always 64x64 tiles); a further level works on 128x128
     // tiles unless the whole inverse or this level is too small to fill the chip with them
     for (int mb64 = 1; mb64 < w.nb; mb64 *= 2) {
@@ -1861,7 +1565,7 @@ int do_trtri(hipStream_t st, const Ws& w) {
         if (!small) {
             const int mb = mb64 / 2, nbt = w.npad / 128;
             const long long tiles = (long long)((nbt + 2 * mb - 1) / (2 * mb)) * mb * mb * w.q;
-            small = tiles < g_trtri_level_small;
+            small = tiles < sc.trtri_level_small;
         }
         const int rc = small ? trtri_level<T, 64>(st, w, mb64) : trtri_level<T, 128>(st, w, mb64 / 2);
         if (rc) return rc;
@@ -1870,11 +1574,11 @@ int do_trtri(hipStream_t st, const Ws& w) {
 }
 
 template <typename T>
-int do_lauum(hipStream_t st, const Ws& w) {
+int do_lauum(hipStream_t st, const Ws& w, const lcgp_sched& sc) {
     GemmArgs g;
     g.sA = g.sB = g.sC = w.mat; g.ldA = g.ldB = g.ldC = w.npad; g.p0 = g.p1 = g.p2 = g.p3 = 0;
     g.A = (T*)(w.base + w.off_W); g.B = g.A; g.C = (T*)(w.base + w.off_V);
-    if (use_small_tiles(w, g_small_tiles_lauum)) {
+    if (use_small_tiles(w, sc.lauum_small_tiles)) {
         g.nb = w.nb;
         return launch_gemm<T, OP_LAUUM, 64>(st, g, w.nb * (w.nb + 1) / 2, w.q);
     }
@@ -1884,60 +1588,10 @@ int do_lauum(hipStream_t st, const Ws& w) {
 }
 
 template <typename T>
-int do_potri(hipStream_t st, const Ws& w) {
-    int rc = do_trtri<T>(st, w);
+int do_potri(hipStream_t st, const Ws& w, const lcgp_sched& sc) {
+    int rc = do_trtri<T>(st, w, sc);
     if (rc) return rc;
-    return do_lauum<T>(st, w);
-}
-
-// view of the workspace restricted to components [k0, k0 + kq)
-inline Ws sub_ws(const Ws& w, int k0, int kq) {
-    Ws v = w;
-    v.q = kq;
-    v.off_M += (size_t)k0 * w.mat * w.esz;
-    v.off_W += (size_t)k0 * w.mat * w.esz;
-    v.off_V += (size_t)k0 * w.mat * w.esz;
-    v.off_b += (size_t)k0 * w.npad * w.esz;
-    v.off_z += (size_t)k0 * w.npad * w.esz;
-    v.off_part += (size_t)k0 * w.ntile_lower * 2 * TS * sizeof(double);
-    v.off_logdet += (size_t)k0 * sizeof(double);
-    v.off_info += (size_t)k0 * sizeof(int);
-    return v;
-}
-
-// A = L L^T and W = L^-1 for all components of w; returns with everything ordered before later work on `st`.
-template <typename T>
-int factor_and_invert_triangle(hipStream_t st, const Ws& w) {
-    const int G = g_groups < 1 ? 1 : (g_groups > MAX_GROUPS ? MAX_GROUPS : g_groups);
-    const int ng = w.q < G ? w.q : G;
-    if (ng <= 1) {
-        int rc = do_potrf<T>(st, w);
-        if (rc) return rc;
-        return do_trtri<T>(st, w);
-    }
-    StreamPool* pool = nullptr;
-    int rc = pool_get(pool);
-    if (rc) return rc;
-    hipError_t e = hipEventRecord(pool->fork, st);
-    if (e != hipSuccess) return fail("hipEventRecord", e);
-    const int base = w.q / ng, extra = w.q % ng;
-    int k0 = 0;
-    for (int g = 0; g < ng; ++g) {
-        const int kq = base + (g < extra ? 1 : 0);
-        const Ws v = sub_ws(w, k0, kq);
-        k0 += kq;
-        e = hipStreamWaitEvent(pool->s[g], pool->fork, 0);
-        if (e != hipSuccess) return fail("hipStreamWaitEvent", e);
-        rc = do_potrf<T>(pool->s[g], v);
-        if (rc) return rc;
-        rc = do_trtri<T>(pool->s[g], v);
-        if (rc) return rc;
-        e = hipEventRecord(pool->join[g], pool->s[g]);
-        if (e != hipSuccess) return fail("hipEventRecord", e);
-        e = hipStreamWaitEvent(st, pool->join[g], 0);
-        if (e != hipSuccess) return fail("hipStreamWaitEvent", e);
-    }
-    return 0;
+    return do_lauum<T>(st, w, sc);
 }
 
 template <typename T, int DD>
@@ -1948,15 +1602,15 @@ void launch_grad(hipStream_t st, const Ws& w, const void* x, const void* sr, con
 }
 
 template <typename T>
-int do_nll_grad(hipStream_t st, const Ws& w, const void* x, const void* Y, const void* sr, const double* theta,
-                double* out) {
+int do_nll_grad(hipStream_t st, const Ws& w, const lcgp_sched& sc, const void* x, const void* Y, const void* sr,
+                const double* theta, double* out) {
     int rc = do_build<T>(st, w, x, sr, theta, Y);
     if (rc) return rc;
     T* b = (T*)(w.base + w.off_b);
     T* z = (T*)(w.base + w.off_z);
-    rc = factor_and_invert_triangle<T>(st, w);
+    rc = do_potrf<T>(st, w, sc);
     if (rc) return rc;
-    rc = do_lauum<T>(st, w);
+    rc = do_potri<T>(st, w, sc);
     if (rc) return rc;
     hipLaunchKernelGGL((symv_tile_kernel<T>), dim3(w.ntile_lower, w.q), dim3(256), 0, st, (const T*)(w.base + w.off_V),
                        w.mat, w.npad, (const T*)b, (double*)(w.base + w.off_part), w.ntile_lower);
@@ -1980,6 +1634,45 @@ int do_nll_grad(hipStream_t st, const Ws& w, const void* x, const void* Y, const
     return 0;
 }
 
+// The rank's share of the reduced vector, assembled on the device (one workgroup, fixed summation order):
+//   vec = [ sum_k (half_logdet_k - quad_k / (2 D_k)) | sum_k info_k | g_ell (q x d) | g_scale (q) | g_nug (q) | g_sigma (p) ]
+// component-local slots are written at the GLOBAL component index comp[i]; g_sigma_a = sum_k psi_k[a] gsig_k[a] / (2 D_k).
+__global__ __launch_bounds__(256) void pack_partial_kernel(int d, int p, int q_local, int q_total,
+                                                           const int* __restrict__ comp, const double* __restrict__ theta,
+                                                           const double* __restrict__ out, double* __restrict__ vec) {
+    const int tid = threadIdx.x;
+    const int tw = d + 3 + p, ow = d + 5 + p;
+    const int off_s = 2 + q_total * d, off_n = off_s + q_total, off_g = off_n + q_total;
+    for (int e = tid; e < off_g; e += 256) vec[e] = 0.0;
+    __syncthreads();
+    if (tid == 0) {
+        double v = 0.0, bad_sum = 0.0;
+        for (int i = 0; i < q_local; ++i) {
+            const double* o = out + (size_t)i * ow;
+            v += o[0] - o[1] / (2.0 * theta[(size_t)i * tw + d + 2]);
+            bad_sum += o[2];
+        }
+        vec[0] = v;
+        vec[1] = bad_sum;
+    }
+    for (int e = tid; e < q_local * (d + 2); e += 256) {
+        const int i = e / (d + 2), j = e - i * (d + 2);
+        const int k = comp[i];
+        const double val = out[(size_t)i * ow + 3 + j];
+        if (j < d) vec[2 + k * d + j] = val;
+        else if (j == d) vec[off_s + k] = val;
+        else vec[off_n + k] = val;
+    }
+    for (int a = tid; a < p; a += 256) {
+        double s = 0.0;
+        for (int i = 0; i < q_local; ++i) {
+            const double* th = theta + (size_t)i * tw;
+            s += 0.5 * th[d + 3 + a] * out[(size_t)i * ow + 5 + d + a] / th[d + 2];
+        }
+        vec[off_g + a] = s;
+    }
+}
+
 int check_common(int dtype, int n, int d, int p, int q) {
     if (dtype != LCGP_F64 && dtype != LCGP_F32) return bad("dtype must be 0 (f64) or 1 (f32)");
     if (n < 1) return bad("n < 1");
@@ -1987,6 +1680,11 @@ int check_common(int dtype, int n, int d, int p, int q) {
     if (p < 1) return bad("p < 1");
     if (q < 1 || q > 65535) return bad("q_local must be in [1, 65535]");
     return 0;
+}
+
+inline int resolve_sched(const lcgp_sched* in, lcgp_sched& out) {
+    out = in ? *in : default_sched();
+    return check_sched(out);
 }
 
 template <typename T>
@@ -2031,100 +1729,22 @@ int do_predict(hipStream_t st, const Ws& w, const void* x, const void* sr, const
 // ---------------------------------------------------------------------------------------------------
 // C ABI
 // ---------------------------------------------------------------------------------------------------
+#ifndef LCGP_SRC_HASH
+#define LCGP_SRC_HASH "unknown"
+#endif
+
 extern "C" {
 
 int lcgp_version(void) { return LCGP_VERSION; }
+const char* lcgp_source_hash(void) { return LCGP_SRC_HASH; }
 const char* lcgp_last_error(void) { return g_err; }
 int lcgp_theta_width(int d, int p) { return d + 3 + p; }
 int lcgp_out_width(int d, int p) { return d + 5 + p; }
+int lcgp_partial_width(int d, int p, int q_total) { return 2 + q_total * d + 2 * q_total + p; }
 
-int lcgp_set_tuning(int key, int value) {
-    if (key == 0) {
-        if (value < 0 || value > 64) return bad("outer panel width must be in [0, 64] blocks (0 = automatic)");
-        g_outer_blocks = value;
-        return 0;
-    }
-    if (key == 2) {
-        g_debug_mask = value;
-        return 0;
-    }
-    if (key == 3) {
-        g_lookahead = value;
-        return 0;
-    }
-    if (key == 4) {
-        g_chain_prio = value ? 1 : 0;
-        return 0;
-    }
-    if (key == 6) {
-        g_small_tiles_trtri = value;
-        return 0;
-    }
-    if (key == 7) {
-        g_small_tiles_lauum = value;
-        return 0;
-    }
-    if (key == 11) {
-        g_fill_leaf = value;
-        return 0;
-    }
-    if (key == 12) {
-        g_step_fused = value ? 1 : 0;
-        return 0;
-    }
-    if (key == 13) {
-        g_fill_step = value;
-        return 0;
-    }
-    if (key == 14) {
-        g_leaf_in_wide = value < 0 ? 0 : value;
-        return 0;
-    }
-    if (key == 15) {
-        g_trtri_level_small = value < 0 ? 0 : value;
-        return 0;
-    }
-    if (key == 10) {
-        g_any_order = value ? 1 : 0;
-        return 0;
-    }
-    if (key == 9) {
-        g_waves128 = value == 4 ? 4 : 8;
-        return 0;
-    }
-    if (key == 8) {
-        g_small_tiles_syrk = value;
-        return 0;
-    }
-    if (key == 5) {
-        if (value < 0 || value > 1024) return bad("super-panel width must be in [0, 1024] blocks");
-        g_super_blocks = value;
-        return 0;
-    }
-    if (key == 1) {
-        if (value < 1 || value > MAX_GROUPS) return bad("component groups must be in [1, 8]");
-        g_groups = value;
-        return 0;
-    }
-    return bad("unknown tuning key");
-}
-
-int lcgp_shutdown(void) {
-    for (int dev = 0; dev < 16; ++dev) {
-        StreamPool& p = g_pool[dev];
-        if (!p.ready) continue;
-        for (int i = 0; i < MAX_GROUPS; ++i) {
-            (void)hipStreamDestroy(p.s[i]);
-            (void)hipEventDestroy(p.join[i]);
-        }
-        (void)hipEventDestroy(p.fork);
-        (void)hipStreamDestroy(p.chain);
-        (void)hipEventDestroy(p.ev_panel);
-        (void)hipEventDestroy(p.ev_next);
-        (void)hipEventDestroy(p.ev_fork2);
-        (void)hipEventDestroy(p.ev_join2);
-        p.ready = false;
-    }
+int lcgp_sched_default(lcgp_sched* sched) {
+    if (!sched) return bad("sched is NULL");
+    *sched = default_sched();
     return 0;
 }
 
@@ -2133,6 +1753,15 @@ int lcgp_workspace_bytes(int dtype, int n, int d, int p, int q_local, size_t* by
     if (rc) return rc;
     if (!bytes) return bad("bytes is NULL");
     *bytes = carve(dtype, n, d, p, q_local, nullptr).total;
+    return 0;
+}
+
+int lcgp_predict_scratch_bytes(int dtype, int n, int q_local, int n0, size_t* bytes) {
+    if (dtype != LCGP_F64 && dtype != LCGP_F32) return bad("dtype must be 0 (f64) or 1 (f32)");
+    if (n < 1 || n0 < 1 || q_local < 1) return bad("n, n0, q_local must be >= 1");
+    if (!bytes) return bad("bytes is NULL");
+    const size_t npad = round_up(n, 2 * TS), n0pad = round_up(n0, TS);
+    *bytes = 2 * n0pad * npad * (dtype == LCGP_F64 ? 8 : 4);
     return 0;
 }
 
@@ -2163,13 +1792,15 @@ int lcgp_kernel_build(void* stream, int dtype, int n, int d, int p, int q_local,
 }
 
 int lcgp_potrf_logdet(void* stream, int dtype, int n, int d, int p, int q_local, void* workspace, double* half_logdet,
-                      int* info) {
+                      int* info, const lcgp_sched* sched) {
     int rc = check_common(dtype, n, d, p, q_local);
     if (rc) return rc;
     if (!workspace) return bad("NULL workspace");
+    lcgp_sched sc;
+    if ((rc = resolve_sched(sched, sc))) return rc;
     Ws w = carve(dtype, n, d, p, q_local, workspace);
     hipStream_t st = (hipStream_t)stream;
-    rc = dtype == LCGP_F64 ? do_potrf<double>(st, w) : do_potrf<float>(st, w);
+    rc = dtype == LCGP_F64 ? do_potrf<double>(st, w, sc) : do_potrf<float>(st, w, sc);
     if (rc) return rc;
     if (half_logdet || info) {
         hipLaunchKernelGGL(copy_stats_kernel, dim3((q_local + 63) / 64), dim3(64), 0, st,
@@ -2180,28 +1811,34 @@ int lcgp_potrf_logdet(void* stream, int dtype, int n, int d, int p, int q_local,
     return 0;
 }
 
-int lcgp_potri(void* stream, int dtype, int n, int d, int p, int q_local, void* workspace) {
+int lcgp_potri(void* stream, int dtype, int n, int d, int p, int q_local, void* workspace, const lcgp_sched* sched) {
     int rc = check_common(dtype, n, d, p, q_local);
     if (rc) return rc;
     if (!workspace) return bad("NULL workspace");
+    lcgp_sched sc;
+    if ((rc = resolve_sched(sched, sc))) return rc;
     Ws w = carve(dtype, n, d, p, q_local, workspace);
-    return dtype == LCGP_F64 ? do_potri<double>((hipStream_t)stream, w) : do_potri<float>((hipStream_t)stream, w);
+    return dtype == LCGP_F64 ? do_potri<double>((hipStream_t)stream, w, sc) : do_potri<float>((hipStream_t)stream, w, sc);
 }
 
-int lcgp_trtri(void* stream, int dtype, int n, int d, int p, int q_local, void* workspace) {
+int lcgp_trtri(void* stream, int dtype, int n, int d, int p, int q_local, void* workspace, const lcgp_sched* sched) {
     int rc = check_common(dtype, n, d, p, q_local);
     if (rc) return rc;
     if (!workspace) return bad("NULL workspace");
+    lcgp_sched sc;
+    if ((rc = resolve_sched(sched, sc))) return rc;
     Ws w = carve(dtype, n, d, p, q_local, workspace);
-    return dtype == LCGP_F64 ? do_trtri<double>((hipStream_t)stream, w) : do_trtri<float>((hipStream_t)stream, w);
+    return dtype == LCGP_F64 ? do_trtri<double>((hipStream_t)stream, w, sc) : do_trtri<float>((hipStream_t)stream, w, sc);
 }
 
-int lcgp_lauum(void* stream, int dtype, int n, int d, int p, int q_local, void* workspace) {
+int lcgp_lauum(void* stream, int dtype, int n, int d, int p, int q_local, void* workspace, const lcgp_sched* sched) {
     int rc = check_common(dtype, n, d, p, q_local);
     if (rc) return rc;
     if (!workspace) return bad("NULL workspace");
+    lcgp_sched sc;
+    if ((rc = resolve_sched(sched, sc))) return rc;
     Ws w = carve(dtype, n, d, p, q_local, workspace);
-    return dtype == LCGP_F64 ? do_lauum<double>((hipStream_t)stream, w) : do_lauum<float>((hipStream_t)stream, w);
+    return dtype == LCGP_F64 ? do_lauum<double>((hipStream_t)stream, w, sc) : do_lauum<float>((hipStream_t)stream, w, sc);
 }
 
 int lcgp_fetch_matrix(void* stream, int dtype, int n, int d, int p, int q_local, const void* workspace, int which, int k,
@@ -2238,13 +1875,26 @@ int lcgp_fetch_vector(void* stream, int dtype, int n, int d, int p, int q_local,
 }
 
 int lcgp_nll_grad(void* stream, int dtype, int n, int d, int p, int q_local, const void* x, const void* Y,
-                  const void* sr, const double* theta, void* workspace, double* out) {
+                  const void* sr, const double* theta, void* workspace, double* out, const lcgp_sched* sched) {
     int rc = check_common(dtype, n, d, p, q_local);
     if (rc) return rc;
     if (!x || !Y || !theta || !workspace || !out) return bad("NULL pointer");
+    lcgp_sched sc;
+    if ((rc = resolve_sched(sched, sc))) return rc;
     Ws w = carve(dtype, n, d, p, q_local, workspace);
-    return dtype == LCGP_F64 ? do_nll_grad<double>((hipStream_t)stream, w, x, Y, sr, theta, out)
-                             : do_nll_grad<float>((hipStream_t)stream, w, x, Y, sr, theta, out);
+    return dtype == LCGP_F64 ? do_nll_grad<double>((hipStream_t)stream, w, sc, x, Y, sr, theta, out)
+                             : do_nll_grad<float>((hipStream_t)stream, w, sc, x, Y, sr, theta, out);
+}
+
+int lcgp_pack_partial(void* stream, int d, int p, int q_local, int q_total, const int* comp, const double* theta,
+                      const double* out, double* vec) {
+    if (d < 1 || d > DMAX || p < 1) return bad("d must be in [1, 16], p >= 1");
+    if (q_local < 0 || q_total < 1 || q_local > q_total) return bad("need 0 <= q_local <= q_total, q_total >= 1");
+    if (!vec || (q_local > 0 && (!comp || !theta || !out))) return bad("NULL pointer");
+    hipLaunchKernelGGL(pack_partial_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, d, p, q_local, q_total, comp, theta,
+                       out, vec);
+    CHECK_LAUNCH("pack_partial_kernel");
+    return 0;
 }
 
 int lcgp_predict(void* stream, int dtype, int n, int d, int p, int q_local, const void* x, const void* sr,

@@ -2,9 +2,14 @@
 
 The q latent components are independent (the reference fans them out over joblib threads,
 lcgp.py:718-720 / 792-794).  Here component k lives on rank k mod G; every rank holds the small replicated
-inputs; one all-reduce(sum) of a (P+1)-vector per evaluation is the only exchange (RCCL over xGMI when the
-process group's backend is "nccl"; gloo in the CPU tests).  Every rank then runs the identical L-BFGS-B step
-on identical numbers, so no broadcast of the next iterate is needed.
+inputs; one all-reduce(sum) of a (P+2)-vector per evaluation is the only exchange.  With the `nccl` backend
+(= RCCL over xGMI) the vector is assembled on the device by the library (lcgp_pack_partial), reduced in
+place and copied to the host ONCE; with `gloo` (the CPU tests) the same calls run on host tensors.  Every rank
+then runs the identical L-BFGS-B step on identical numbers, so no broadcast of the next iterate is needed.
+
+Collectives are used when the job has more than one rank, or when a process group was passed explicitly
+(`LCGP(..., process_group=g)`): a one-rank RCCL group then still goes through every collective, which is how
+the production path is exercised on a single-GPU test box.
 """
 from __future__ import annotations
 
@@ -16,16 +21,29 @@ def _dist():
     return dist
 
 
-def is_distributed(group=None) -> bool:
+def _initialized() -> bool:
     try:
         dist = _dist()
     except Exception:
         return False
-    return dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+    return dist.is_available() and dist.is_initialized()
+
+
+def is_distributed(group=None) -> bool:
+    return _initialized() and _dist().get_world_size(group) > 1
+
+
+def use_collectives(group=None) -> bool:
+    """More than one rank, or an explicitly passed process group (even of one rank)."""
+    return _initialized() and (group is not None or _dist().get_world_size() > 1)
+
+
+def backend_is_nccl(group=None) -> bool:
+    return _initialized() and str(_dist().get_backend(group)) == "nccl"
 
 
 def rank_world(group=None):
-    if not is_distributed(group):
+    if not _initialized() or not use_collectives(group):
         return 0, 1
     dist = _dist()
     return dist.get_rank(group), dist.get_world_size(group)
@@ -36,23 +54,28 @@ def local_components(q: int, rank: int, world: int):
     return list(range(rank, q, world))
 
 
-def _all_reduce_impl(vec, group=None, device=None):
-    """The collective itself (also exercised on a 1-rank RCCL group by tests/test_gpu_api.py)."""
+def reduce_to_host(t, group=None):
+    """Sum the float64 torch tensor `t` over the ranks IN PLACE where it lives (device tensor + nccl: RCCL, no host
+    round trip before the collective) and return it as a numpy array: exactly one device-to-host copy."""
     import torch
-    dist = _dist()
-    t = torch.as_tensor(np.ascontiguousarray(vec, np.float64))
-    backend = dist.get_backend(group)
-    if backend == "nccl":
-        t = t.to(device if device is not None else torch.device("cuda", torch.cuda.current_device()))
-    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    if use_collectives(group):
+        dist = _dist()
+        if backend_is_nccl(group):
+            if not t.is_cuda:
+                t = t.to(torch.device("cuda", torch.cuda.current_device()))
+        elif t.is_cuda:
+            t = t.cpu()          # gloo rehearsal of a GPU job: the collective runs on host memory
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
     return t.cpu().numpy()
 
 
 def all_reduce_sum(vec, group=None, device=None):
     """Sum a float64 numpy vector over the ranks (returns a new numpy array, identical on all ranks)."""
-    if not is_distributed(group):
-        return np.asarray(vec, np.float64)
-    return _all_reduce_impl(vec, group, device)
+    import torch
+    t = torch.as_tensor(np.ascontiguousarray(vec, np.float64)).clone()
+    if use_collectives(group) and backend_is_nccl(group):
+        t = t.to(device if device is not None else torch.device("cuda", torch.cuda.current_device()))
+    return reduce_to_host(t, group)
 
 
 def gather_rows(local_rows, q: int, group=None, device=None):
@@ -64,24 +87,20 @@ def gather_rows(local_rows, q: int, group=None, device=None):
     ks = local_components(q, rank, world)
     if len(ks):
         full[ks] = local_rows
-    if world == 1:
+    if not use_collectives(group):
         return full
     # disjoint rows: a sum is a gather
     return all_reduce_sum(full.reshape(-1), group, device).reshape(q, m)
 
 
-def _broadcast_impl(arr, src=0, group=None, device=None):
+def broadcast_array(arr, src=0, group=None, device=None):
+    """Every rank returns rank `src`'s float64 array (used so that all ranks share ONE SVD basis)."""
+    if not use_collectives(group):
+        return np.asarray(arr, np.float64)
     import torch
     dist = _dist()
     t = torch.as_tensor(np.ascontiguousarray(arr, np.float64)).clone()
-    if dist.get_backend(group) == "nccl":
+    if backend_is_nccl(group):
         t = t.to(device if device is not None else torch.device("cuda", torch.cuda.current_device()))
     dist.broadcast(t, src=dist.get_global_rank(group, src) if group is not None else src, group=group)
     return t.cpu().numpy()
-
-
-def broadcast_array(arr, src=0, group=None, device=None):
-    """Every rank returns rank `src`'s float64 array (used so that all ranks share ONE SVD basis)."""
-    if not is_distributed(group):
-        return np.asarray(arr, np.float64)
-    return _broadcast_impl(arr, src, group, device)

@@ -13,11 +13,19 @@ from . import _hip
 
 _DT = {"float64": _hip.F64, "f64": _hip.F64, "float32": _hip.F32, "f32": _hip.F32}
 
+# rows of x0 handled per lcgp_predict call: bounds the scratch (2 * q_local * chunk * npad elements) however many
+# new inputs a caller passes (the reference has no limit on n0 either)
+PREDICT_CHUNK = 2048
+
 
 class HotPathEngine:
-    """Holds x (n,d), Y (p,n), optional sr (n) and the workspace for `q_local` components on one GPU."""
+    """Holds x (n,d), Y (p,n), optional sr (n) and the workspace for the local components on one GPU.
 
-    def __init__(self, x, Y, sr=None, q_local=1, dtype="float64", device=None):
+    `comp_ids` are the GLOBAL indices of the local components (k -> rank k mod G) and `q_total` the number of
+    components over all ranks; they place this rank's gradient slots in the vector the ranks all-reduce
+    (`evaluate_partial`).  Defaults: a single rank holding components 0 .. q_local-1."""
+
+    def __init__(self, x, Y, sr=None, q_local=1, dtype="float64", device=None, comp_ids=None, q_total=None):
         import torch
         _hip.require_gpu()
         self.lib = _hip.load()
@@ -32,6 +40,11 @@ class HotPathEngine:
         self.p = Y.shape[0]
         assert Y.shape[1] == self.n
         self.q_local = int(q_local)
+        comp_ids = list(range(self.q_local)) if comp_ids is None else [int(k) for k in comp_ids]
+        assert len(comp_ids) == self.q_local
+        self.q_total = int(q_total) if q_total is not None else (max(comp_ids) + 1 if comp_ids else 1)
+        assert all(0 <= k < self.q_total for k in comp_ids)
+        self.sched = None            # an _hip.Sched to override the launch schedule (tests / tools); None = defaults
         with torch.cuda.device(self.device):
             self.x = torch.as_tensor(x).to(self.device, self.tdtype).contiguous()
             self.Y = torch.as_tensor(Y).to(self.device, self.tdtype).contiguous()
@@ -44,9 +57,17 @@ class HotPathEngine:
             self.workspace = torch.empty(self.workspace_bytes, dtype=torch.uint8, device=self.device)
             self.tw = self.lib.lcgp_theta_width(self.d, self.p)
             self.ow = self.lib.lcgp_out_width(self.d, self.p)
+            self.pw = self.lib.lcgp_partial_width(self.d, self.p, self.q_total)
             self.theta_dev = torch.zeros((self.q_local, self.tw), dtype=torch.float64, device=self.device)
-            self.theta_pin = torch.zeros((self.q_local, self.tw), dtype=torch.float64).pin_memory()
+            # two pinned staging rows used alternately: the H2D copy of one evaluation may still be in flight when the
+            # host packs the next one (evaluate() itself synchronises, enqueue-style callers do not)
+            self._theta_pin = [torch.zeros((self.q_local, self.tw), dtype=torch.float64).pin_memory() for _ in range(2)]
+            self._pin_event = [None, None]
+            self._pin_next = 0
             self.out_dev = torch.zeros((self.q_local, self.ow), dtype=torch.float64, device=self.device)
+            self.comp_dev = torch.as_tensor(np.asarray(comp_ids, np.int32)).to(self.device)
+            self.partial_dev = torch.zeros(self.pw, dtype=torch.float64, device=self.device)
+            self._scratch = None
         self._theta_last = None
 
     # ------------------------------------------------------------------------------------------------
@@ -56,10 +77,22 @@ class HotPathEngine:
     def _p(self, t):
         return C.c_void_p(0 if t is None else t.data_ptr())
 
+    def _sched(self):
+        return None if self.sched is None else C.byref(self.sched)
+
     def upload_theta(self, theta_rows):
+        torch = self.torch
         theta_rows = np.asarray(theta_rows, dtype=np.float64).reshape(self.q_local, self.tw)
-        self.theta_pin.copy_(self.torch.from_numpy(theta_rows))
-        self.theta_dev.copy_(self.theta_pin, non_blocking=True)
+        i = self._pin_next
+        self._pin_next ^= 1
+        if self._pin_event[i] is not None:
+            self._pin_event[i].synchronize()      # the copy that last read this staging buffer has completed
+        self._theta_pin[i].copy_(torch.from_numpy(theta_rows))
+        with torch.cuda.device(self.device):
+            self.theta_dev.copy_(self._theta_pin[i], non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(self.device))
+        self._pin_event[i] = ev
         self._theta_last = theta_rows.copy()
 
     def enqueue(self):
@@ -67,7 +100,8 @@ class HotPathEngine:
         with self.torch.cuda.device(self.device):
             _hip.check(self.lib.lcgp_nll_grad(self._stream(), self.dtype, self.n, self.d, self.p, self.q_local,
                                               self._p(self.x), self._p(self.Y), self._p(self.sr),
-                                              self._p(self.theta_dev), self._p(self.workspace), self._p(self.out_dev)),
+                                              self._p(self.theta_dev), self._p(self.workspace), self._p(self.out_dev),
+                                              self._sched()),
                        "lcgp_nll_grad")
 
     def evaluate(self, theta_rows):
@@ -76,37 +110,60 @@ class HotPathEngine:
         self.enqueue()
         return self.out_dev.cpu().numpy()
 
-    def evaluate_device(self, theta_rows):
-        """Same, leaving the output block on the device (for an RCCL reduction before the D2H copy)."""
+    def evaluate_partial(self, theta_rows):
+        """theta rows -> this rank's share of the reduced vector, LEFT ON THE DEVICE (lcgp_pack_partial): the caller
+        all-reduces it in place over the ranks (RCCL) and copies it to the host once."""
         self.upload_theta(theta_rows)
         self.enqueue()
-        return self.out_dev
+        with self.torch.cuda.device(self.device):
+            _hip.check(self.lib.lcgp_pack_partial(self._stream(), self.d, self.p, self.q_local, self.q_total,
+                                                  self._p(self.comp_dev), self._p(self.theta_dev), self._p(self.out_dev),
+                                                  self._p(self.partial_dev)), "lcgp_pack_partial")
+        return self.partial_dev
 
     def is_current(self, theta_rows):
         return self._theta_last is not None and np.array_equal(
             self._theta_last, np.asarray(theta_rows, np.float64).reshape(self.q_local, self.tw))
 
     # ------------------------------------------------------------------------------------------------
-    def predict(self, x0s, same=False):
-        """ghat, gvar (q_local, n0) for standardised x0s, from the factorisation of the last evaluate()."""
+    def predict_device(self, x0s, same=False):
+        """ghat, gvar (q_local, n0) float64 DEVICE tensors for standardised x0s, from the factorisation of the last
+        evaluate().  x0 is processed in chunks of PREDICT_CHUNK rows with one engine-owned scratch buffer."""
         torch = self.torch
         if self._theta_last is None:
             raise RuntimeError("predict() needs a preceding evaluate() at the current parameters")
         x0s = np.ascontiguousarray(x0s, np.float64)
         n0 = x0s.shape[0]
         assert x0s.shape[1] == self.d
-        npad = (self.n + 127) // 128 * 128
-        n0pad = (n0 + 63) // 64 * 64
+        chunk = min(n0, PREDICT_CHUNK)
         with torch.cuda.device(self.device):
             x0d = torch.as_tensor(x0s).to(self.device, self.tdtype).contiguous()
-            scratch = torch.empty(2 * n0pad * npad, dtype=self.tdtype, device=self.device)
+            nbytes = C.c_size_t(0)
+            _hip.check(self.lib.lcgp_predict_scratch_bytes(self.dtype, self.n, self.q_local, chunk, C.byref(nbytes)),
+                       "lcgp_predict_scratch_bytes")
+            if self._scratch is None or self._scratch.numel() < nbytes.value:
+                self._scratch = None
+                self._scratch = torch.empty(int(nbytes.value), dtype=torch.uint8, device=self.device)
             ghat = torch.empty((self.q_local, n0), dtype=torch.float64, device=self.device)
             gvar = torch.empty((self.q_local, n0), dtype=torch.float64, device=self.device)
-            _hip.check(self.lib.lcgp_predict(self._stream(), self.dtype, self.n, self.d, self.p, self.q_local,
-                                             self._p(self.x), self._p(self.sr), self._p(self.theta_dev),
-                                             self._p(self.workspace), n0, self._p(x0d), int(bool(same)),
-                                             self._p(scratch), self._p(ghat), self._p(gvar)), "lcgp_predict")
-            return ghat.cpu().numpy(), gvar.cpu().numpy()
+            for lo in range(0, n0, chunk):
+                m = min(chunk, n0 - lo)
+                # the nugget term only exists when x0 IS the training set (covmat.py:46-51): then n0 == n and the
+                # diagonal of the full cross matrix falls on rows lo .. lo+m of this chunk
+                gh = torch.empty((self.q_local, m), dtype=torch.float64, device=self.device)
+                gv = torch.empty((self.q_local, m), dtype=torch.float64, device=self.device)
+                _hip.check(self.lib.lcgp_predict(self._stream(), self.dtype, self.n, self.d, self.p, self.q_local,
+                                                 self._p(self.x), self._p(self.sr), self._p(self.theta_dev),
+                                                 self._p(self.workspace), m, C.c_void_p(x0d.data_ptr() + lo * self.d * x0d.element_size()),
+                                                 (1 + lo) if same else 0,
+                                                 self._p(self._scratch), self._p(gh), self._p(gv)), "lcgp_predict")
+                ghat[:, lo:lo + m] = gh
+                gvar[:, lo:lo + m] = gv
+            return ghat, gvar
+
+    def predict(self, x0s, same=False):
+        ghat, gvar = self.predict_device(x0s, same)
+        return ghat.cpu().numpy(), gvar.cpu().numpy()
 
     def fetch_vector(self, which, k):
         torch = self.torch

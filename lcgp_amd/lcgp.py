@@ -70,7 +70,7 @@ class LCGP:
         self._dtype = dtype
         self._group = process_group
         self._engine = None
-        self._aux_valid = False
+        self._u_last = None          # unconstrained vector the factorisation in the workspace belongs to
         self._aux_override = {}
 
         self.x = self._verify_data_types(x)
@@ -103,7 +103,7 @@ class LCGP:
             self.y, self.ymean, self.ystd, _ = self.init_standard_y(self.y)
 
         self.g, self.phi, self.diag_D, self.q = self.init_phi(var_threshold=var_threshold)
-        if _dist.is_distributed(self._group):
+        if _dist.use_collectives(self._group):
             # the SVD basis is only defined up to column signs: all ranks must use rank 0's
             dev = torch.device(device) if device is not None else None
             self.phi = _t(_dist.broadcast_array(_np(self.phi), 0, self._group, dev))
@@ -347,11 +347,17 @@ class LCGP:
         self.lLmb0.unconstrained = u[a:a + q].copy()
         self.lnugGPs.unconstrained = u[a + q:a + 2 * q].copy()
         self.lsigma2s.unconstrained = u[a + 2 * q:a + 2 * q + ns].copy()
-        self._invalidate()
+        self._aux_override = {}
 
     def _invalidate(self):
-        self._aux_valid = False
+        self._u_last = None
         self._aux_override = {}
+
+    @property
+    def _aux_valid(self):
+        """True when the workspace holds L, L^-1, A^-1, z of the CURRENT parameter vector (so `predict()` right after
+        `fit()` does not pay another evaluation: L-BFGS-B's last evaluation normally is its final iterate)."""
+        return self._u_last is not None and not self._aux_override and np.array_equal(self._u_last, self._get_flat())
 
     # =============================================================================================
     # the hot path (lcgp.py:537-666 + the gpflow/TF gradient tape)
@@ -367,8 +373,9 @@ class LCGP:
             sr = np.sqrt(_np(self.r))
             ybar_used = _np(self.ybar_s if self.rep_standardize_ybar else self.ybar)
             return HotPathEngine(_np(self.x_unique_s), ybar_used * sr[None, :], sr, len(self._local_ks),
-                                 self._dtype, self._device)
-        return HotPathEngine(_np(self.x), _np(self.y), None, len(self._local_ks), self._dtype, self._device)
+                                 self._dtype, self._device, comp_ids=self._local_ks, q_total=self.q)
+        return HotPathEngine(_np(self.x), _np(self.y), None, len(self._local_ks), self._dtype, self._device,
+                             comp_ids=self._local_ks, q_total=self.q)
 
     def _get_engine(self):
         if self._engine is None:
@@ -399,31 +406,39 @@ class LCGP:
         rows = [np.concatenate([lLmb[k], [lLmb0[k], lnug[k], D[k]], phi[:, k] / sig_eff]) for k in self._local_ks]
         return np.asarray(rows, F64).reshape(len(self._local_ks), int(self.d) + 3 + int(self.p))
 
+    def _zeros_on_device(self, shape):
+        """A zero tensor where this rank's collectives run (a rank without components has no engine)."""
+        if self._engine is not None:
+            dev = self._engine.device
+        elif _dist.backend_is_nccl(self._group):
+            dev = torch.device(self._device) if self._device is not None else torch.device('cuda', torch.cuda.current_device())
+        else:
+            dev = torch.device('cpu')
+        return torch.zeros(shape, dtype=torch.float64, device=dev)
+
     def _run_path(self):
         """One evaluation at the current parameters: returns (value, gradient w.r.t. the CONSTRAINED
-        parameters in flat order lLmb, lLmb0, lnugGPs, lsigma2s).  Rep values already carry the 1/n."""
+        parameters in flat order lLmb, lLmb0, lnugGPs, lsigma2s).  Rep values already carry the 1/n.
+
+        The rank's share [nll, info, g_lLmb (q d), g_lLmb0 (q), g_lnug (q), g_ls2_built (p)] is assembled ON THE
+        DEVICE (lcgp_pack_partial), all-reduced in place (RCCL when the group's backend is nccl) and copied to
+        the host once."""
         eng = self._get_engine()
-        self._u_last = self._get_flat().copy()
+        u_now = self._get_flat().copy()
+        self._u_last = None
         n, d, p, q = int(self.n), int(self.d), int(self.p), int(self.q)
         es = np.asarray(self.diag_error_structure, int)
         ls2_b = np.repeat(self.lsigma2s.numpy(), es)
         sig_eff = np.exp(0.5 * ls2_b) / self._std
-        phi, D = _np(self.phi), _np(self.diag_D)
-        # partial (P_b + 2)-vector of this rank: [nll, info, g_lLmb (q d), g_lLmb0 (q), g_lnug (q), g_ls2_built (p)]
-        vec = np.zeros(2 + q * d + 2 * q + p, F64)
         if eng is not None:
-            out = eng.evaluate(self._theta_rows(sig_eff))
-            for row, k in zip(out, self._local_ks):
-                vec[0] += row[0] - row[1] / (2.0 * D[k])
-                vec[1] += row[2]
-                vec[2 + k * d:2 + (k + 1) * d] = row[3:3 + d]
-                vec[2 + q * d + k] = row[3 + d]
-                vec[2 + q * d + q + k] = row[4 + d]
-                vec[2 + q * d + 2 * q:] += 0.5 / sig_eff * phi[:, k] * row[5 + d:5 + d + p] / D[k]
-        vec = _dist.all_reduce_sum(vec, self._group, None if eng is None else eng.device)
+            part = eng.evaluate_partial(self._theta_rows(sig_eff))
+        else:
+            part = self._zeros_on_device(2 + q * d + 2 * q + p)
+        vec = _dist.reduce_to_host(part, self._group)
         if vec[1] != 0 or not np.isfinite(vec[0]):
             raise np.linalg.LinAlgError(
                 'I + D_k C_k is not numerically positive definite at the current parameters (info=%g)' % vec[1])
+        self._u_last = u_now         # the workspace now holds L, L^-1, A^-1, z at these parameters
         nll = vec[0] + 0.5 * np.sum(self._ysq / sig_eff ** 2) + n / 2.0 * np.sum(ls2_b - 2.0 * np.log(self._std)) \
             - 0.5 * p * self._sum_log_r
         g_b = vec[2 + q * d + 2 * q:] + n / 2.0 - 0.5 * self._ysq / sig_eff ** 2
@@ -442,15 +457,32 @@ class LCGP:
                               self.lLmb0.transform.dforward(self.lLmb0.unconstrained),
                               self.lnugGPs.transform.dforward(self.lnugGPs.unconstrained),
                               np.ones(self.lsigma2s.size, F64)])
-        self._aux_valid = True   # the workspace now holds L, L^-1, A^-1, z at the current parameters
         return val, g * jac
 
     def fit(self, verbose=False):
-        """scipy L-BFGS-B with default options on the unconstrained vector (lcgp.py:537-540)."""
+        """scipy L-BFGS-B with default options on the unconstrained vector (lcgp.py:537-540).
+
+        A trial point at which some I + D_k C_k is not numerically positive definite (possible in float32 or at the
+        SoftClip edges) does not abort the fit: the reference's eigendecomposition form returns a non-finite or huge
+        value there and the line search backs off, so the closure reports a huge finite value with a zero gradient.
+        `loss()` / `neglpost()` called directly still raise.  (info is all-reduced, so every rank takes the same branch.)"""
         if self.submethod not in self.submethod_loss_map:
             raise ValueError("Invalid submethod. Choices are 'full' or 'rep'.")
         u0 = self._get_flat()
-        res = sopt.minimize(lambda u: self.loss_and_grad(u), u0, jac=True, method='L-BFGS-B')
+        first = []
+
+        def fun(u):
+            try:
+                val, g = self.loss_and_grad(u)
+            except np.linalg.LinAlgError:
+                if not first:
+                    raise
+                return 1e10 + 1e6 * abs(first[0]), np.zeros_like(u)
+            if not first:
+                first.append(val)
+            return val, g
+
+        res = sopt.minimize(fun, u0, jac=True, method='L-BFGS-B')
         self._set_flat(res.x)
         self.opt_result = res
         return
@@ -465,14 +497,12 @@ class LCGP:
         """lcgp.py:635-666 (value only; a 0-d float64 tensor)."""
         self._require_mode('full')
         val, _ = self._run_path()
-        self._aux_valid = True
         return torch.tensor(val, dtype=torch.float64)
 
     def neglpost_rep(self):
         """lcgp.py:554-630."""
         self._require_mode('rep')
         val, _ = self._run_path()
-        self._aux_valid = True
         return torch.tensor(val, dtype=torch.float64)
 
     def _require_mode(self, mode):
@@ -499,14 +529,12 @@ class LCGP:
         if hasattr(self, 'x_unique') and hasattr(self, 'ybar'):
             self._compute_aux_predictive_quantities_rep()
             return
-        self._run_path()
-        self._aux_valid = True
         self._aux_override = {}
+        self._run_path()
 
     def _compute_aux_predictive_quantities_rep(self):
-        self._run_path()
-        self._aux_valid = True
         self._aux_override = {}
+        self._run_path()
         ls2_b = _np(self.get_param()[2])
         sis = np.exp(-0.5 * ls2_b) * self._std
         phi = _np(self.phi)
@@ -521,27 +549,32 @@ class LCGP:
         eng = self._get_engine()
         # rank-independent test (all ranks must enter the collective together): is the factorisation in the
         # workspace the one of the current parameter vector?
-        stale = getattr(self, '_u_last', None) is None or not np.array_equal(self._u_last, self._get_flat())
-        if (not self._aux_valid) or self._aux_override or stale:
+        if not self._aux_valid:
             self.compute_aux_predictive_quantities()
         return eng
 
     def _latent_predict(self, x0):
-        """ghat, gvar (q, n0) for raw-scale x0 (lcgp.py:822-838 / 877-900)."""
+        """ghat, gvar (q, n0) for raw-scale x0 (lcgp.py:822-838 / 877-900): the local components' rows are computed
+        and placed on the device, ONE all-reduce of the zero-padded (2, q, n0) block gathers them, one D2H copy."""
         eng = self._ensure_aux()
         x0n = _np(x0)
         x0s = (x0n - _np(self.x_min)) / (_np(self.x_max) - _np(self.x_min))
         xtrain = _np(self.x_unique_s if self.submethod == 'rep' else self.x)
         # the nugget is added iff x0 and the training inputs agree in shape and value (covmat.py:46-51)
         same = (x0s.shape == xtrain.shape) and bool(np.all(x0s == xtrain))
-        n0 = x0s.shape[0]
-        if eng is not None:
-            gh, gv = eng.predict(x0s, same)
+        n0, q = x0s.shape[0], int(self.q)
+        if eng is not None and not _dist.use_collectives(self._group):
+            gh, gv = eng.predict_device(x0s, same)
+            both = torch.stack([gh, gv]).cpu().numpy()
         else:
-            gh = gv = np.zeros((0, n0))
-        dev = None if eng is None else eng.device
-        ghat = _dist.gather_rows(gh, int(self.q), self._group, dev)
-        gvar = _dist.gather_rows(gv, int(self.q), self._group, dev)
+            full = self._zeros_on_device((2, q, n0))
+            if eng is not None:
+                gh, gv = eng.predict_device(x0s, same)
+                idx = torch.as_tensor(self._local_ks, dtype=torch.long, device=full.device)
+                full[0].index_copy_(0, idx, gh.to(full.device))
+                full[1].index_copy_(0, idx, gv.to(full.device))
+            both = _dist.reduce_to_host(full, self._group)      # disjoint rows: a sum is a gather
+        ghat, gvar = both[0], both[1]
         self.ghat, self.gvar = _t(ghat), _t(gvar)
         return ghat, gvar
 
@@ -592,14 +625,17 @@ class LCGP:
     def _fetch_all(self, fn, width):
         eng = self._engine
         rows = np.zeros((len(self._local_ks), width), F64)
-        for i in range(len(self._local_ks)):
-            rows[i] = fn(eng, i).reshape(-1)
+        if eng is not None:
+            for i in range(len(self._local_ks)):
+                rows[i] = fn(eng, i).reshape(-1)
         return _dist.gather_rows(rows, int(self.q), self._group, None if eng is None else eng.device)
 
     def _cache_get(self, name):
         if name in self._aux_override:
             return self._aux_override[name]
-        if not self._aux_valid or self._engine is None:
+        # rank-independent decision (a rank without components has no engine but must still enter the gather):
+        # only the validity of the factorisation counts, never whether THIS rank holds an engine
+        if not self._aux_valid:
             n = int(self.n)
             if name in ('CinvMs', 'mks'):
                 return torch.full((int(self.q), n), float('nan'), dtype=torch.float64)
@@ -628,7 +664,6 @@ class LCGP:
 
     def _cache_set(self, name, value):
         self._aux_override[name] = value
-        self._aux_valid = False
 
     CinvMs = property(lambda self: self._cache_get('CinvMs'), lambda self, v: self._cache_set('CinvMs', v))
     mks = property(lambda self: self._cache_get('mks'), lambda self, v: self._cache_set('mks', v))

@@ -50,15 +50,46 @@ def eigh_form_component(x, y, phi_k, d_k, ell, scale, nug, ls2_built, threads=No
                                          ls2=e_t.grad.numpy())
 
 
-def chol_form_component(x, y, phi_k, d_k, ell, scale, nug, ls2_built):
-    """Same component in the Cholesky form with closed-form gradients; returns (seconds, pieces)."""
+def chol_form_component(x, y, phi_k, d_k, ell, scale, nug, ls2_built, threads=None):
+    """Same component in the Cholesky form with closed-form gradients, on all host threads
+    (torch CPU: MKL potrf / potri, threaded elementwise passes); returns (seconds, pieces)."""
+    import torch
+    if threads:
+        torch.set_num_threads(int(threads))
+    xt = torch.as_tensor(np.asarray(x, np.float64))
+    yt = torch.as_tensor(np.asarray(y, np.float64))
+    ell = np.asarray(ell, np.float64)
+    n, d = xt.shape
     t0 = time.perf_counter()
     sig = np.exp(0.5 * np.asarray(ls2_built, np.float64))
-    b = y.T @ (phi_k / sig)
-    low, c0, s_all, half_logdet, z = orc._chol_component(np.asarray(x, np.float64), ell, scale, nug, d_k, b)
-    ge, gs, gn = orc._kernel_param_grads(low, c0, s_all, z, d_k, ell, scale, nug)
+    b = yt.T @ torch.as_tensor(np.asarray(phi_k, np.float64) / sig)
+    a = xt / torch.as_tensor(ell)
+    c0 = torch.ones((n, n), dtype=torch.float64)
+    v = torch.zeros((n, n), dtype=torch.float64)
+    for j in range(d):                                         # covmat.py:37-41
+        s = (a[:, j].reshape(-1, 1) - a[:, j]).abs_()
+        c0.mul_(1 + s)
+        v.sub_(s)
+    c0.mul_(v.exp_())
+    nt = nug / (1.0 + nug)
+    amat = (d_k * scale * (1.0 - nt)) * c0
+    amat.diagonal().add_(1.0 + d_k * scale * nt)
+    low = torch.linalg.cholesky(amat)
+    half_logdet = float(torch.log(low.diagonal()).sum())
+    ainv = torch.cholesky_inverse(low)
+    z = ainv @ b
+    gmat = (0.5 * d_k) * ainv - 0.5 * torch.outer(z, z)
+    gc0 = gmat * c0                                            # shared by every parameter's contraction
+    g_ell = np.empty(d)
+    for j in range(d):
+        sj = (a[:, j].reshape(-1, 1) - a[:, j]).abs_()
+        g_ell[j] = scale * (1.0 - nt) / ell[j] * float((gc0 * (sj * sj / (1.0 + sj))).sum())
+    tr_g = float(gmat.diagonal().sum())
+    g_c0 = float(gc0.sum())
+    g_scale = (1.0 - nt) * g_c0 + nt * tr_g
+    g_nug = scale * (tr_g - g_c0) / (1.0 + nug) ** 2
     quad = float(b @ (b - z))
-    gsig = y @ (b - z)
+    gsig = (yt @ (b - z)).numpy()
     dt = time.perf_counter() - t0
-    return dt, dict(half_logdet=half_logdet, quad=quad, g_ell=ge, g_scale=gs, g_nug=gn, gsig=gsig,
+    return dt, dict(half_logdet=half_logdet, quad=quad, g_ell=g_ell, g_scale=g_scale, g_nug=g_nug, gsig=gsig,
                     value=half_logdet - quad / (2.0 * d_k))

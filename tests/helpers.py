@@ -11,7 +11,9 @@ from oracle import lcgp_oracle as orc
 class OracleEngine:
     device = None
 
-    def __init__(self, x, Y, sr=None, q_local=1, dtype='float64', device=None):
+    def __init__(self, x, Y, sr=None, q_local=1, dtype='float64', device=None, comp_ids=None, q_total=None):
+        self.comp_ids = list(range(q_local)) if comp_ids is None else list(comp_ids)
+        self.q_total = q_local if q_total is None else q_total
         self.x = np.asarray(x, np.float64)
         self.Y = np.asarray(Y, np.float64)
         self.sr = None if sr is None else np.asarray(sr, np.float64)
@@ -35,6 +37,28 @@ class OracleEngine:
             state.append((th.copy(), low, z, b))
         self._state = state
         return out
+
+    def evaluate_partial(self, theta_rows):
+        """What lcgp_pack_partial assembles on the device (include/lcgp_hip.h), as a CPU torch tensor."""
+        import torch
+        theta_rows = np.asarray(theta_rows, np.float64)
+        out = self.evaluate(theta_rows)
+        d, p, q = self.d, self.p, self.q_total
+        vec = np.zeros(2 + q * d + 2 * q + p)
+        for row, th, k in zip(out, theta_rows, self.comp_ids):
+            D, psi = th[d + 2], th[d + 3:]
+            vec[0] += row[0] - row[1] / (2.0 * D)
+            vec[1] += row[2]
+            vec[2 + k * d:2 + (k + 1) * d] = row[3:3 + d]
+            vec[2 + q * d + k] = row[3 + d]
+            vec[2 + q * d + q + k] = row[4 + d]
+            vec[2 + q * d + 2 * q:] += 0.5 * psi * row[5 + d:5 + d + p] / D
+        return torch.as_tensor(vec)
+
+    def predict_device(self, x0s, same=False):
+        import torch
+        gh, gv = self.predict(x0s, same)
+        return torch.as_tensor(gh), torch.as_tensor(gv)
 
     def predict(self, x0s, same=False):
         n0 = x0s.shape[0]
@@ -83,8 +107,10 @@ def patch_engine(model):
         if model.submethod == 'rep':
             sr = _np.sqrt(model.r.numpy().astype(float))
             yb = (model.ybar_s if model.rep_standardize_ybar else model.ybar).numpy()
-            return OracleEngine(model.x_unique_s.numpy(), yb * sr[None, :], sr, len(model._local_ks))
-        return OracleEngine(model.x.numpy(), model.y.numpy(), None, len(model._local_ks))
+            return OracleEngine(model.x_unique_s.numpy(), yb * sr[None, :], sr, len(model._local_ks),
+                                comp_ids=model._local_ks, q_total=model.q)
+        return OracleEngine(model.x.numpy(), model.y.numpy(), None, len(model._local_ks),
+                            comp_ids=model._local_ks, q_total=model.q)
 
     model._make_engine = _make
     return model

@@ -183,7 +183,7 @@ static void run_case(int n, int d, int p, int q, bool rep, unsigned seed) {
     }
     report("kernel_build A", e_build, sizeof(T) == 8 ? 1e-14 : 1e-6);
 
-    LCHK(lcgp_potrf_logdet(nullptr, dtype, n, d, p, q, ws, dld, dinfo));
+    LCHK(lcgp_potrf_logdet(nullptr, dtype, n, d, p, q, ws, dld, dinfo, nullptr));
     HIPCHK(hipDeviceSynchronize());
     vec hld(q);
     std::vector<int> hinfo(q);
@@ -206,7 +206,7 @@ static void run_case(int n, int d, int p, int q, bool rep, unsigned seed) {
     report("potrf L", e_l, eps);
     report("potrf half_logdet", e_ld, eps);
 
-    LCHK(lcgp_potri(nullptr, dtype, n, d, p, q, ws));
+    LCHK(lcgp_potri(nullptr, dtype, n, d, p, q, ws, nullptr));
     HIPCHK(hipDeviceSynchronize());
     double e_w = 0, e_v = 0;
     for (int k = 0; k < q; ++k) {
@@ -230,7 +230,7 @@ static void run_case(int n, int d, int p, int q, bool rep, unsigned seed) {
 
     // whole path
     HIPCHK(hipMemset(ws, 0xff, wsb));
-    LCHK(lcgp_nll_grad(nullptr, dtype, n, d, p, q, dx, dY, srp, dtheta, ws, dout));
+    LCHK(lcgp_nll_grad(nullptr, dtype, n, d, p, q, dx, dY, srp, dtheta, ws, dout, nullptr));
     HIPCHK(hipDeviceSynchronize());
     vec hout((size_t)q * ow);
     HIPCHK(hipMemcpy(hout.data(), dout, hout.size() * 8, hipMemcpyDeviceToHost));

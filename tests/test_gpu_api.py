@@ -10,6 +10,14 @@ from lcgp_amd import LCGP
 pytestmark = pytest.mark.gpu
 
 
+def test_native_library_is_the_one_running():
+    """The library loaded in THIS process (on the GPU box: the prebuilt .so that travelled with the snapshot) was
+    compiled from exactly the lcgp_hip.hip / lcgp_hip.h in the tree."""
+    from lcgp_amd import _hip
+    assert _hip.loaded_hash() == _hip.source_hash()
+    assert _hip.load().lcgp_version() >= 200
+
+
 def _rep_data(seed=0, n_unique=20, p=4, d=2, reps=3):
     rng = np.random.default_rng(seed)
     xu = rng.uniform(0, 1, (n_unique, d))
@@ -81,29 +89,118 @@ def test_second_fit_invalidates_prediction_caches():
     assert np.max(np.abs(p0 - p1)) > 1e-8
 
 
-def test_rccl_collectives_on_a_one_rank_group():
-    """The N > 1 bench runs over RCCL (backend "nccl"), which this one-GPU box cannot form with several ranks; a 1-rank
-    RCCL group still goes through the same code: host vector -> device -> all_reduce / broadcast -> host."""
+def test_production_path_over_a_one_rank_rccl_group():
+    """The N > 1 bench runs over RCCL (backend "nccl"), which this one-GPU box cannot form with several ranks.  A 1-rank
+    RCCL group passed explicitly (`process_group=`) FORCES every collective of the production path -- the broadcast of
+    the SVD basis in the constructor, the in-place all-reduce of the device-resident partial vector in every
+    evaluation, the (2, q, n0) gather in predict(), the cache gathers -- through RCCL, and the results must equal the
+    collective-free run and the oracle."""
     import os
     import tempfile
     import torch
     import torch.distributed as dist
     from lcgp_amd import dist as ldist
+    from lcgp_amd import synth
+    from oracle import lcgp_oracle as orc
     if dist.is_initialized():
         pytest.skip('a process group already exists in this process')
     store = tempfile.NamedTemporaryFile(delete=False)
     store.close()
+    calls = {'all_reduce': 0, 'broadcast': 0}
+    real_ar, real_bc = dist.all_reduce, dist.broadcast
+
+    def spy_ar(t, *a, **k):
+        assert t.is_cuda and t.dtype == torch.float64        # reduced where it lives: no host round trip
+        calls['all_reduce'] += 1
+        return real_ar(t, *a, **k)
+
+    def spy_bc(t, *a, **k):
+        calls['broadcast'] += 1
+        return real_bc(t, *a, **k)
+
     try:
         dist.init_process_group('nccl', init_method='file://' + store.name, rank=0, world_size=1,
                                 device_id=torch.device('cuda', torch.cuda.current_device()))
-        v = np.arange(131, dtype=np.float64) / 7.0
-        got = ldist._all_reduce_impl(v)
-        assert got.dtype == np.float64 and np.array_equal(got, v)
-        got = ldist._broadcast_impl(v.reshape(1, -1), 0)
-        assert got.shape == (1, 131) and np.array_equal(got.ravel(), v)
+        grp = dist.group.WORLD
+        assert ldist.use_collectives(grp) and ldist.backend_is_nccl(grp) and not ldist.is_distributed(grp)
+        dist.all_reduce, dist.broadcast = spy_ar, spy_bc
+        for mode, q, maker in (('full', 3, lambda: synth.make_full(901, 200, 2, 4, 3)),
+                               ('rep', 4, lambda: synth.make_rep(902, 60, 3, 2, 4, 4))):
+            x, y = maker()
+            m0 = LCGP(y=y, x=x, q=q, submethod=mode)
+            m = LCGP(y=y, x=x, q=q, submethod=mode, process_group=grp)
+            assert calls['broadcast'] >= 3                    # phi, g, diag_D
+            o = orc.OracleLCGP(y=y, x=x, q=q, submethod=mode)
+            o.phi = m.phi.numpy().copy()
+            u = synth.param_points(901, o.get_unconstrained())[1]
+            n_before = calls['all_reduce']
+            v, g = m.loss_and_grad(u)
+            assert calls['all_reduce'] == n_before + 1        # ONE collective per evaluation
+            v0, g0 = m0.loss_and_grad(u)
+            v2, g2 = o.loss_and_grad_unconstrained(u)
+            assert v == v0 and np.array_equal(g, g0)
+            assert abs(v - v2) <= 1e-6 * abs(v2) and np.max(np.abs(g - g2)) <= 1e-5 * np.max(np.abs(g2))
+            m.fit()
+            m0.fit()
+            assert np.array_equal(m._get_flat(), m0._get_flat())
+            n_before = calls['all_reduce']
+            x0 = np.random.default_rng(3).uniform(0, 1, (9, 2))
+            got = m.predict(x0)
+            assert calls['all_reduce'] - n_before <= 2        # (the factorisation is still valid after fit) + ONE gather
+            want = m0.predict(x0)
+            for a, b in zip(got, want):
+                if a is not None:
+                    np.testing.assert_array_equal(a.numpy(), b.numpy())
+            np.testing.assert_array_equal(m.CinvMs.numpy(), m0.CinvMs.numpy())
         dist.barrier()
     finally:
+        dist.all_reduce, dist.broadcast = real_ar, real_bc
         if dist.is_initialized():
             dist.destroy_process_group()
         if os.path.exists(store.name):
             os.unlink(store.name)
+
+
+def test_predict_after_fit_reuses_the_factorisation():
+    """fit() ends on the point L-BFGS-B evaluated last; predict() must not pay another evaluation for it."""
+    from lcgp_amd import synth
+    x, y = synth.make_full(903, 150, 2, 4, 3)
+    m = LCGP(y=y, x=x, q=3)
+    m.fit()
+    if not np.array_equal(m._u_last, m._get_flat()):
+        pytest.skip('the optimiser returned an earlier iterate than the last one evaluated')
+    eng = m._get_engine()
+    count = {'n': 0}
+    real = eng.evaluate_partial
+
+    def spy(theta):
+        count['n'] += 1
+        return real(theta)
+    eng.evaluate_partial = spy
+    m.predict(x[:7])
+    assert count['n'] == 0
+    m.lsigma2s.assign(m.lsigma2s.numpy() + 0.1)              # any parameter change invalidates it
+    m.predict(x[:7])
+    assert count['n'] == 1
+
+
+def test_predict_chunks_agree_with_one_call():
+    """x0 is processed in chunks of engine.PREDICT_CHUNK rows (bounded scratch); the nugget term of
+    predict(training inputs) must land on the right rows of every chunk."""
+    import lcgp_amd.engine as eng_mod
+    from lcgp_amd import synth
+    x, y = synth.make_full(904, 330, 2, 3, 2)
+    m = LCGP(y=y, x=x, q=2)
+    m.lnugGPs.assign(np.full(2, 0.05))                        # a visible nugget
+    x0 = np.random.default_rng(9).uniform(0, 1, (301, 2))
+    ref_new = [t.numpy() for t in m.predict(x0)]
+    ref_train = [t.numpy() for t in m.predict(x)]
+    old = eng_mod.PREDICT_CHUNK
+    try:
+        eng_mod.PREDICT_CHUNK = 128
+        for a, b in zip(m.predict(x0), ref_new):
+            np.testing.assert_allclose(a.numpy(), b, rtol=1e-12, atol=1e-13)
+        for a, b in zip(m.predict(x), ref_train):
+            np.testing.assert_allclose(a.numpy(), b, rtol=1e-12, atol=1e-13)
+    finally:
+        eng_mod.PREDICT_CHUNK = old

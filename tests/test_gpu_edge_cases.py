@@ -127,39 +127,44 @@ def test_c_abi_argument_checks():
     assert lib.lcgp_workspace_bytes(2, 10, 2, 2, 1, C.byref(nbytes)) < 0          # bad dtype
     assert lib.lcgp_workspace_bytes(0, 0, 2, 2, 1, C.byref(nbytes)) < 0           # n < 1
     assert lib.lcgp_workspace_bytes(0, 10, 2, 2, 0, C.byref(nbytes)) < 0          # q_local < 1
-    assert lib.lcgp_nll_grad(None, 0, 10, 2, 2, 1, None, None, None, None, None, None) < 0
+    assert lib.lcgp_nll_grad(None, 0, 10, 2, 2, 1, None, None, None, None, None, None, None) < 0
     assert b'NULL' in lib.lcgp_last_error()
-    assert lib.lcgp_set_tuning(99, 1) < 0
-    assert lib.lcgp_set_tuning(0, 4) == 0
-    assert lib.lcgp_set_tuning(0, 0) == 0
+    bad = _hip.default_sched()
+    bad.outer_blocks = 65
+    assert lib.lcgp_potri(None, 0, 10, 2, 2, 1, C.c_void_p(8), C.byref(bad)) < 0     # rejected before any launch
+    assert b'outer_blocks' in lib.lcgp_last_error()
 
 
-def _reset_tuning(lib):
-    for key, val in ((0, 0), (5, 0), (1, 1), (3, 0), (2, 0), (12, 1), (11, 248), (13, 248), (14, 1024), (8, 2000), (15, 600)):
-        lib.lcgp_set_tuning(key, val)
+def _sched(**fields):
+    """The default launch schedule with some fields replaced (lcgp_sched travels with every call: no global state)."""
+    sc = _hip.default_sched()
+    for k, v in fields.items():
+        assert hasattr(sc, k), k
+        setattr(sc, k, v)
+    return sc
 
 
-def test_tuning_knobs_do_not_change_results():
-    """Every schedule / kernel variant selectable through lcgp_set_tuning computes the same numbers:
-    panel widths, super-panels, stream groups, look-ahead, three-launch chain steps (key 12 = 0), the
-    barrier-per-pivot-pair diagonal block (key 2 bit 2), no filler / different filler sizes."""
+def test_schedule_parameters_do_not_change_results():
+    """Every launch schedule selectable through lcgp_sched computes the same numbers: panel widths, no filler /
+    different filler sizes, with and without the trailing update that factors the next diagonal block, tile sizes of
+    the inverse."""
     x, y = synth.make_full(326, 700, 3, 4, 4)
     m = LCGP(y=y, x=x, q=4)
     u = synth.param_points(326, m._get_flat())[1]
     ref_v, ref_g = m.loss_and_grad(u)
-    lib = _hip.load()
+    eng = m._get_engine()
     try:
-        for settings in (((0, 2),), ((0, 8),), ((5, 8),), ((1, 2),), ((3, 1),), ((12, 0),), ((2, 4),),
-                         ((12, 0), (2, 4)), ((11, 0), (13, 0)), ((11, 16), (13, 24)), ((0, 3),), ((0, 3), (12, 0)), ((14, 0),), ((14, 100000),),
-                         ((14, 100000), (2, 4)), ((14, 100000), (0, 2)), ((15, 0),), ((15, 100000), (6, 0))):
-            for key, val in settings:
-                assert lib.lcgp_set_tuning(key, val) == 0
+        for fields in (dict(outer_blocks=2), dict(outer_blocks=8), dict(outer_blocks=3), dict(outer_blocks=1),
+                       dict(fill_leaf=0, fill_step=0), dict(fill_leaf=16, fill_step=24), dict(leaf_in_wide=0),
+                       dict(leaf_in_wide=100000), dict(leaf_in_wide=100000, outer_blocks=2), dict(trtri_level_small=0),
+                       dict(trtri_level_small=100000, trtri_small_tiles=0), dict(lauum_small_tiles=0),
+                       dict(lauum_small_tiles=100000, trtri_small_tiles=100000)):
+            eng.sched = _sched(**fields)
             v, g = m.loss_and_grad(u)
-            assert abs(v - ref_v) <= 1e-11 * abs(ref_v), settings
-            assert np.max(np.abs(g - ref_g)) <= 1e-10 * np.max(np.abs(ref_g)), settings
-            _reset_tuning(lib)
+            assert abs(v - ref_v) <= 1e-11 * abs(ref_v), fields
+            assert np.max(np.abs(g - ref_g)) <= 1e-10 * np.max(np.abs(ref_g)), fields
     finally:
-        _reset_tuning(lib)
+        eng.sched = None
 
 
 def test_wide_tile_schedules_agree_at_medium_size():
@@ -170,37 +175,31 @@ def test_wide_tile_schedules_agree_at_medium_size():
     m = LCGP(y=y, x=x, q=4)
     u = synth.param_points(327, m._get_flat())[1]
     ref_v, ref_g = m.loss_and_grad(u)
-    lib = _hip.load()
+    eng = m._get_engine()
     try:
-        for settings in (((8, 16),), ((8, 16), (14, 0)), ((8, 16), (12, 0)), ((8, 16), (14, 100000)), ((8, 16), (11, 40), (13, 56)),
-                         ((8, 16), (0, 2)), ((8, 16), (0, 8)), ((8, 200), (14, 300)), ((8, 16), (2, 4))):
-            for key, val in settings:
-                assert lib.lcgp_set_tuning(key, val) == 0
+        for fields in (dict(syrk_small_tiles=16), dict(syrk_small_tiles=16, leaf_in_wide=0),
+                       dict(syrk_small_tiles=16, leaf_in_wide=100000), dict(syrk_small_tiles=16, fill_leaf=40, fill_step=56),
+                       dict(syrk_small_tiles=16, outer_blocks=2), dict(syrk_small_tiles=16, outer_blocks=8),
+                       dict(syrk_small_tiles=200, leaf_in_wide=300), dict(syrk_small_tiles=1, fill_leaf=8, fill_step=8)):
+            eng.sched = _sched(**fields)
             v, g = m.loss_and_grad(u)
-            assert abs(v - ref_v) <= 1e-11 * abs(ref_v), settings
-            assert np.max(np.abs(g - ref_g)) <= 1e-10 * np.max(np.abs(ref_g)), settings
-            _reset_tuning(lib)
+            assert abs(v - ref_v) <= 1e-11 * abs(ref_v), fields
+            assert np.max(np.abs(g - ref_g)) <= 1e-10 * np.max(np.abs(ref_g)), fields
     finally:
-        _reset_tuning(lib)
+        eng.sched = None
 
 
 def test_chain_variants_match_oracle_at_several_sizes():
     """The fused chain step and the in-wave diagonal block against the oracle where the panel structure differs:
     a single block, a partial panel, several panels with a ragged last one."""
-    lib = _hip.load()
-    try:
-        for seed, n in ((331, 64), (332, 200), (333, 330), (334, 900)):
-            x, y = synth.make_full(seed, n, 2, 6, 2)
-            o = orc.OracleLCGP(y=y, x=x, q=2)
-            u = synth.param_points(seed, o.get_unconstrained())[1]
-            for settings in ((), ((12, 0),), ((2, 4),), ((14, 0),)):
-                for key, val in settings:
-                    assert lib.lcgp_set_tuning(key, val) == 0
-                m = LCGP(y=y, x=x, q=2)
-                _same(m, o, u)
-                _reset_tuning(lib)
-    finally:
-        _reset_tuning(lib)
+    for seed, n in ((331, 64), (332, 200), (333, 330), (334, 900)):
+        x, y = synth.make_full(seed, n, 2, 6, 2)
+        o = orc.OracleLCGP(y=y, x=x, q=2)
+        u = synth.param_points(seed, o.get_unconstrained())[1]
+        for fields in ({}, dict(leaf_in_wide=0), dict(outer_blocks=3)):
+            m = LCGP(y=y, x=x, q=2)
+            m._get_engine().sched = _sched(**fields)
+            _same(m, o, u)
 
 
 def _first_bad_pivot(a):
@@ -215,11 +214,10 @@ def _first_bad_pivot(a):
     return 0
 
 
-@pytest.mark.parametrize('variant', [(), ((2, 4),), ((12, 0),), ((14, 0),)])
+@pytest.mark.parametrize('variant', [{}, dict(leaf_in_wide=0), dict(outer_blocks=2), dict(fill_leaf=0, fill_step=0)])
 def test_info_is_the_first_bad_pivot(variant):
     """info of the output block = position of the first non-positive pivot (as LAPACK dpotrf reports it), wherever
     it falls: first block, inside a later 16-column panel of a diagonal block, in a later block or panel."""
-    lib = _hip.load()
     x, y = synth.make_full(340, 330, 2, 4, 3)
     m = LCGP(y=y, x=x, q=3)
     ell, scale, nug = m.lLmb.numpy(), m.lLmb0.numpy(), m.lnugGPs.numpy()
@@ -237,12 +235,8 @@ def test_info_is_the_first_bad_pivot(variant):
     m.diag_D = torch.as_tensor(np.array(dvals))
     eng = m._get_engine()
     sig_eff = np.exp(0.5 * np.repeat(m.lsigma2s.numpy(), np.asarray(m.diag_error_structure, int))) / m._std
-    try:
-        for key, val in variant:
-            assert lib.lcgp_set_tuning(key, val) == 0
-        out = eng.evaluate(m._theta_rows(sig_eff))
-    finally:
-        _reset_tuning(lib)
+    eng.sched = _sched(**variant)
+    out = eng.evaluate(m._theta_rows(sig_eff))
     assert [int(r[2]) for r in out] == want
 
 
@@ -250,28 +244,24 @@ def test_random_shapes_and_schedules_against_oracle():
     """Seeded sweep: random (n, d, p, q) with a random schedule variant each, NLL and gradient against the oracle.
     (sizes up to a few panels; the tolerances are the parity bar of the path: 1e-6 / 1e-5 relative)"""
     rng = np.random.default_rng(20260401)
-    lib = _hip.load()
-    variants = [(), ((12, 0),), ((2, 4),), ((14, 0),), ((14, 100000),), ((0, 2),), ((0, 3),), ((0, 8),), ((11, 8), (13, 16)),
-                ((8, 1),), ((8, 1), (14, 100000)), ((8, 1), (11, 24), (13, 40))]
-    try:
-        for case in range(14):
-            n = int(rng.integers(1, 3)) if case == 0 else int(rng.integers(2, 1100))
-            d = int(rng.integers(1, 5))
-            p = int(rng.integers(1, 7))
-            q = int(rng.integers(1, min(p, 3) + 1))
-            seed = 5000 + case
-            x, y = synth.make_full(seed, max(n, 2), d, p, q)
-            kw = dict(q=q, robust_mean=n > 8)
-            o = orc.OracleLCGP(y=y, x=x, **kw)
-            u = synth.param_points(seed, o.get_unconstrained())[1 if n > 8 else 0]
-            settings = variants[int(rng.integers(0, len(variants)))]
-            for key, val in settings:
-                assert lib.lcgp_set_tuning(key, val) == 0
-            m = LCGP(y=y, x=x, **kw)
-            try:
-                _same(m, o, u)
-            except AssertionError as e:
-                raise AssertionError('case %d: n=%d d=%d p=%d q=%d settings=%r: %s' % (case, n, d, p, q, settings, e))
-            _reset_tuning(lib)
-    finally:
-        _reset_tuning(lib)
+    variants = [{}, dict(leaf_in_wide=0), dict(leaf_in_wide=100000), dict(outer_blocks=2), dict(outer_blocks=3),
+                dict(outer_blocks=8), dict(fill_leaf=8, fill_step=16), dict(syrk_small_tiles=1),
+                dict(syrk_small_tiles=1, leaf_in_wide=100000), dict(syrk_small_tiles=1, fill_leaf=24, fill_step=40),
+                dict(trtri_small_tiles=0, trtri_level_small=0, lauum_small_tiles=0)]
+    for case in range(14):
+        n = int(rng.integers(1, 3)) if case == 0 else int(rng.integers(2, 1100))
+        d = int(rng.integers(1, 5))
+        p = int(rng.integers(1, 7))
+        q = int(rng.integers(1, min(p, 3) + 1))
+        seed = 5000 + case
+        x, y = synth.make_full(seed, max(n, 2), d, p, q)
+        kw = dict(q=q, robust_mean=n > 8)
+        o = orc.OracleLCGP(y=y, x=x, **kw)
+        u = synth.param_points(seed, o.get_unconstrained())[1 if n > 8 else 0]
+        fields = variants[int(rng.integers(0, len(variants)))]
+        m = LCGP(y=y, x=x, **kw)
+        m._get_engine().sched = _sched(**fields)
+        try:
+            _same(m, o, u)
+        except AssertionError as e:
+            raise AssertionError('case %d: n=%d d=%d p=%d q=%d sched=%r: %s' % (case, n, d, p, q, fields, e))

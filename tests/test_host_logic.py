@@ -281,6 +281,21 @@ def test_c_abi_library_exports_every_declared_symbol():
     assert nbytes.value >= 3 * 8 * 4096 * 4096 * 8
     assert lib.lcgp_workspace_bytes(0, 4096, 99, 64, 8, C.byref(nbytes)) < 0      # d > 16 refused
     assert b'd must be' in lib.lcgp_last_error()
+    assert lib.lcgp_partial_width(6, 64, 8) == 2 + 8 * 6 + 2 * 8 + 64
+    sc = _hip.default_sched()                   # schedule parameters travel per call: the library has no setters
+    assert sc.outer_blocks == 0 and sc.fill_leaf > 0 and sc.syrk_small_tiles > 0
+    assert not any(n.startswith(('lcgp_set', 'lcgp_shutdown')) for n in declared)
+
+
+def test_native_library_is_the_one_built_from_these_sources():
+    """The shared object carries the sha256 of the sources it was compiled from (lcgp_source_hash()); build() and the
+    loader compare it with the tree, so a stale prebuilt binary cannot pass for the current kernels (neither here nor
+    on the GPU box, where the prebuilt .so travels with the snapshot)."""
+    from lcgp_amd import _hip
+    _hip.build_library()
+    assert _hip.binary_hash() == _hip.source_hash()
+    assert _hip.loaded_hash() == _hip.source_hash()
+    assert not _hip.needs_build()
 
 
 @pytest.mark.skipif(torch.cuda.is_available(), reason="checks the no-GPU behaviour")

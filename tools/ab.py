@@ -1,8 +1,9 @@
-"""A/B timing of tuning settings inside ONE process on ONE box (box-to-box noise is +-3 %).
+"""A/B timing of launch schedules inside ONE process on ONE box (box-to-box noise is +-3 %).
 
-usage: python tools/ab.py [--q Q] [--n N] [--reps R] [--steps K] "name:key=val,key=val" "name2:..." ...
-Each setting is a comma-separated list of lcgp_set_tuning key=value pairs (empty = defaults).  The settings are
-timed round-robin R times, K evaluations each; prints the min and mean ms per evaluation and the potrf stage time.
+usage: python tools/ab.py [--q Q] [--n N] [--reps R] [--steps K] "name:field=val,field=val" "name2:..." ...
+Each setting is a comma-separated list of lcgp_sched field=value pairs (include/lcgp_hip.h; empty = defaults), passed
+per call through the engine -- the library has no global tuning state.  The settings are timed round-robin R times,
+K evaluations each; prints the min and mean ms per evaluation.
 """
 import argparse
 import sys
@@ -14,7 +15,6 @@ import torch
 sys.path.insert(0, '.')
 from lcgp_amd import LCGP, synth, _hip  # noqa: E402
 
-DEFAULTS = {0: 0, 1: 1, 2: 0, 3: 0, 5: 0, 6: 4200, 7: 2048, 8: 2000, 9: 8, 10: 0, 11: 248, 12: 1, 13: 248, 14: 1024, 15: 600}
 
 
 def main():
@@ -34,24 +34,25 @@ def main():
     a.n = x.shape[0]
     dtype = 'float64' if cfg['dtype'] == 'f64' else 'float32'
     m = LCGP(y=y, x=x, q=a.q, dtype=dtype)          # q components = one rank's share of the configuration
-    lib = _hip.load()
     u = m._get_flat()
     eng = None
     res = {}
     names = []
     for s in a.settings:
         name, _, kv = s.partition(':')
-        pairs = [tuple(int(t) for t in p.split('=')) for p in kv.split(',') if p]
+        pairs = [(p.split('=')[0], int(p.split('=')[1])) for p in kv.split(',') if p]
         names.append((name, pairs))
         res[name] = []
 
-    def apply(pairs):
-        for k, v in DEFAULTS.items():
-            lib.lcgp_set_tuning(k, v)
-        for k, v in pairs:
-            assert lib.lcgp_set_tuning(k, v) == 0, (k, v)
-
     eng = m._get_engine()
+
+    def apply(pairs):
+        sc = _hip.default_sched()
+        for k, v in pairs:
+            assert hasattr(sc, k), k
+            setattr(sc, k, v)
+        eng.sched = sc
+
     sig_eff = np.exp(0.5 * np.repeat(m.lsigma2s.numpy(), np.asarray(m.diag_error_structure, int))) / m._std
     theta = m._theta_rows(sig_eff)
     eng.evaluate(theta)
