@@ -267,7 +267,12 @@ def test_fit_matches_oracle_fit_full_path():
     o.phi = m.phi.numpy().copy()
     m.fit()
     o.fit()
-    assert abs(float(m.loss()) - o.loss()) <= 2e-5 * abs(o.loss())
+    # where each run stops along the flat directions (nuggets at their bound) depends on round-off in the last digits of
+    # the gradient; the two optima agree to the optimiser's tolerance, and at the GPU's optimum both implementations
+    # compute the SAME objective (the parity statement proper)
+    assert abs(float(m.loss()) - o.loss()) <= 1e-4 * abs(o.loss())
+    v_at, _ = o.loss_and_grad_unconstrained(m._get_flat())
+    assert abs(float(m.loss()) - v_at) <= 1e-9 * abs(v_at)
     # each implementation's optimum is (nearly) stationary for the OTHER one as well
     _, g = o.loss_and_grad_unconstrained(m._get_flat())
     assert np.max(np.abs(g)) <= 1e-2 * max(1.0, abs(o.loss()))
