@@ -4,7 +4,10 @@ The reference itself cannot be imported in the build container (tensorflow / tfp
 so these vectors come from the oracle, which is pinned by the reference's stored notebook outputs
 (KAT-1 / KAT-2) and by the cross-identities in tests/test_oracle_identities.py.
 
-    python tests/golden/make_golden.py
+    python tests/golden/make_golden.py            # small cases  -> lcgp_golden.npz        (seconds)
+    python tests/golden/make_golden.py --large    # BASELINE.json's full-size configurations -> lcgp_golden_large.npz
+                                                  # (n=4096 q=8 fp64; rep n_unique=2048 x 5; the 4096-point prefix of
+                                                  #  the n=16384 fp32 configuration in fp64) -- about 5 minutes of CPU
 
 Inputs are regenerated from seeds (lcgp_amd/synth.py, tests/kat_data.py); only expected outputs are
 stored: NLL, gradient w.r.t. the unconstrained vector, per-component pieces, and a few predictions.
@@ -42,9 +45,22 @@ def case_models():
     yield 'cfg2_n1024', 2, orc.OracleLCGP(y=y, x=x, q=cfg['q'], submethod='full'), None
 
 
-def main():
+def large_case_models():
+    """BASELINE.json configs[2], [4] and (its 4096-point prefix, fp64 oracle values for the fp32 run) [3]."""
+    x, y, cfg = synth.make_config(3)
+    yield 'cfg3_n4096', 3, orc.OracleLCGP(y=y, x=x, q=cfg['q'], submethod='full'), \
+        np.random.default_rng(30).uniform(0, 1, (10, cfg['d']))
+    x, y, cfg = synth.make_config(5)
+    yield 'cfg5_rep_n2048x5', 5, orc.OracleLCGP(y=y, x=x, q=cfg['q'], submethod='rep'), \
+        np.random.default_rng(50).uniform(0, 1, (10, cfg['d']))
+    x, y, cfg = synth.make_config(4)
+    yield 'cfg4_prefix4096', 4, orc.OracleLCGP(y=y[:, :4096], x=x[:4096], q=cfg['q'], submethod='full'), \
+        np.random.default_rng(40).uniform(0, 1, (10, cfg['d']))
+
+
+def generate(cases, fname):
     out = {}
-    for name, c, m, x0 in case_models():
+    for name, c, m, x0 in cases:
         pts = synth.param_points(c, m.get_unconstrained())
         vals, grads = [], []
         for u in pts:
@@ -64,9 +80,16 @@ def main():
             out[name + '/yconfvar'] = pred[2]
             if m.submethod == 'full':
                 out[name + '/fullcov'] = pred[3]
-        print(name, 'n=%d q=%d' % (m.n, m.q), 'nll', vals)
-    np.savez_compressed(os.path.join(HERE, 'lcgp_golden.npz'), **out)
-    print('wrote', os.path.join(HERE, 'lcgp_golden.npz'))
+        print(name, 'n=%d q=%d' % (m.n, m.q), 'nll', vals, flush=True)
+    np.savez_compressed(os.path.join(HERE, fname), **out)
+    print('wrote', os.path.join(HERE, fname))
+
+
+def main():
+    if '--large' in sys.argv[1:]:
+        generate(large_case_models(), 'lcgp_golden_large.npz')
+    else:
+        generate(case_models(), 'lcgp_golden.npz')
 
 
 if __name__ == '__main__':

@@ -1,0 +1,135 @@
+"""Every BASELINE.json configuration at FULL size through the HIP path (`pytest -m gpu`).
+
+Expected values are committed fixtures (tests/golden/lcgp_golden_large.npz, written by
+`python tests/golden/make_golden.py --large` from the pinned CPU oracle); inputs are regenerated from seeds
+(lcgp_amd/synth.py), so nothing but numbers travels to the GPU box.
+
+  configs[1]  n=1024  d=3  p=16 q=4 fp64           -> tests/test_gpu_parity.py (lcgp_golden.npz: cfg2_n1024)
+  configs[2]  n=4096  d=6  p=64 q=8 fp64           -> test_cfg3_*   (NLL + all 130 gradient entries at 3 points, predictions)
+  configs[3]  n=16384 d=10 p=32 q=8 fp32           -> test_cfg4_*   (fp32 vs the fp64 oracle on the 4096-point prefix; the
+                                                      full size through properties: fp32 vs this build's fp64 path, A^-1 A,
+                                                      bitwise repeatability)
+  configs[4]  rep n_unique=2048 x 5, d=3, q=6 fp64 -> test_cfg5_*   (NLL + gradient at 3 points, 10 predictions)
+
+Tolerances: BASELINE.json's bar for fp64 (NLL 1e-6 relative, gradient 1e-5 relative to max |g|).  fp32 has no
+reference (the reference is float64-only): NLL 1e-3 relative, gradient 2e-2 relative to max |g|.
+"""
+import os
+import time
+
+import numpy as np
+import pytest
+
+from lcgp_amd import LCGP, synth
+
+pytestmark = pytest.mark.gpu
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+GOLD = np.load(os.path.join(HERE, 'golden', 'lcgp_golden_large.npz'))
+
+NLL_TOL, GRAD_TOL = 1e-6, 1e-5          # BASELINE.json north_star
+NLL_TOL32, GRAD_TOL32 = 1e-3, 2e-2      # float32 (this build's own statement)
+
+
+def _check_points(m, name, nll_tol, grad_tol):
+    worst_v = worst_g = 0.0
+    for i, u in enumerate(GOLD[name + '/u']):
+        v, g = m.loss_and_grad(u)
+        want_v, want_g = GOLD[name + '/nll'][i], GOLD[name + '/grad'][i]
+        assert g.shape == want_g.shape
+        e_v = abs(v - want_v) / abs(want_v)
+        e_g = np.max(np.abs(g - want_g)) / np.max(np.abs(want_g))
+        worst_v, worst_g = max(worst_v, e_v), max(worst_g, e_g)
+        assert e_v <= nll_tol, (name, i, v, want_v)
+        assert e_g <= grad_tol, (name, i, e_g)
+    print('%s: worst NLL rel err %.2e, worst gradient err / max|g| %.2e over %d points, %d gradient entries each'
+          % (name, worst_v, worst_g, len(GOLD[name + '/u']), GOLD[name + '/grad'].shape[1]))
+
+
+def _check_predictions(m, name, rtol, atol_frac):
+    m._set_flat(GOLD[name + '/u'][1])
+    got = m.predict(GOLD[name + '/x0'], return_fullcov=(name + '/fullcov') in GOLD.files)
+    for key, arr in zip(('ypred', 'ypredvar', 'yconfvar'), got[:3]):
+        want = GOLD[name + '/' + key]
+        np.testing.assert_allclose(arr.numpy(), want, rtol=rtol, atol=atol_frac * np.max(np.abs(want)), err_msg=key)
+    if (name + '/fullcov') in GOLD.files:
+        want = GOLD[name + '/fullcov']
+        np.testing.assert_allclose(got[3].numpy(), want, rtol=rtol, atol=atol_frac * np.max(np.abs(want)))
+
+
+def test_cfg3_headline_size_nll_every_gradient_entry_and_predictions():
+    """n=4096, d=6, p=64 -> q=8, fp64 (lcgp.py:635-666 + the gradient tape; predictions lcgp.py:808-859)."""
+    x, y, cfg = synth.make_config(3)
+    t0 = time.perf_counter()
+    m = LCGP(y=y, x=x, q=cfg['q'])
+    print('cfg3 constructor %.2f s' % (time.perf_counter() - t0))
+    assert GOLD['cfg3_n4096/grad'].shape == (3, 8 * 6 + 2 * 8 + 64)
+    np.testing.assert_allclose(np.sort(m.diag_D.numpy()), np.sort(GOLD['cfg3_n4096/diag_D']), rtol=1e-9)
+    _check_points(m, 'cfg3_n4096', NLL_TOL, GRAD_TOL)
+    _check_predictions(m, 'cfg3_n4096', 1e-6, 1e-8)
+
+
+def test_cfg5_replicated_2048x5_nll_gradient_and_predictions():
+    """n_unique=2048 x 5 replicates, d=3, p=12 -> q=6, submethod='rep', fp64 (lcgp.py:554-630, 864-930)."""
+    x, y, cfg = synth.make_config(5)
+    t0 = time.perf_counter()
+    m = LCGP(y=y, x=x, q=cfg['q'], submethod='rep')
+    t_ctor = time.perf_counter() - t0
+    print('cfg5 constructor (N=%d rows -> n_unique=%d) %.2f s' % (x.shape[0], int(m.n), t_ctor))
+    assert int(m.n) == 2048 and np.all(m.r.numpy() == 5)
+    _check_points(m, 'cfg5_rep_n2048x5', NLL_TOL, GRAD_TOL)
+    _check_predictions(m, 'cfg5_rep_n2048x5', 1e-6, 1e-8)
+    assert t_ctor < 20.0
+
+
+def test_cfg4_float32_against_the_fp64_oracle_on_the_4096_prefix():
+    """The fp32 path (512-wide outer panels: 8 of them here) against fp64 oracle values: d=10, p=32 -> q=8."""
+    x, y, cfg = synth.make_config(4)
+    m = LCGP(y=y[:, :4096], x=x[:4096], q=cfg['q'], dtype='float32')
+    _check_points(m, 'cfg4_prefix4096', NLL_TOL32, GRAD_TOL32)
+    _check_predictions(m, 'cfg4_prefix4096', 2e-2, 2e-3)
+    # and the fp64 path on the same fixture at the fp64 bar (d = 10 exercises the widest fused-gradient instantiation)
+    m64 = LCGP(y=y[:, :4096], x=x[:4096], q=cfg['q'])
+    _check_points(m64, 'cfg4_prefix4096', NLL_TOL, GRAD_TOL)
+
+
+def test_cfg4_full_size_float32_properties():
+    """n=16384, d=10, p=32 -> q=8 in float32 (32 outer panels of 512 columns; 3 x 8.6 GB of matrices).  No CPU oracle
+    finishes this size in seconds, so the full-size run is checked through size-independent properties:
+      * positive definite everywhere (info = 0), finite value and gradient;
+      * bitwise identical when repeated (no atomics, fixed summation orders);
+      * float32 against THIS build's float64 path on the same inputs at the stated float32 tolerance (the float64
+        path is the one checked against the oracle at every size the oracle can reach);
+      * A^-1 A = I on sampled columns, with A recomputed in float64 on the host."""
+    from oracle import lcgp_oracle as orc
+    x, y, cfg = synth.make_config(4)
+    n = x.shape[0]
+    t0 = time.perf_counter()
+    m = LCGP(y=y, x=x, q=cfg['q'], dtype='float32')
+    t_ctor = time.perf_counter() - t0
+    print('cfg4 constructor (n=%d) %.2f s' % (n, t_ctor))
+    assert t_ctor < 20.0
+    u = synth.param_points(4, m._get_flat())[1]
+    v1, g1 = m.loss_and_grad(u)
+    assert np.isfinite(v1) and np.all(np.isfinite(g1))
+    v2, g2 = m.loss_and_grad(u)
+    assert v1 == v2 and np.array_equal(g1, g2)
+    # A^-1 A on sampled columns of component 0
+    eng = m._get_engine()
+    ainv = eng.fetch_matrix(2, 0)
+    ell, scale, nug, D = m.lLmb.numpy()[0], m.lLmb0.numpy()[0], m.lnugGPs.numpy()[0], m.diag_D.numpy()[0]
+    cols = np.array([0, 63, 64, 511, 512, 513, 5000, 8191, 8192, 12345, n - 65, n - 1])
+    xs = m.x.numpy()
+    a_cols = D * orc.matern32(xs, xs[cols], ell, scale, nug)
+    a_cols[cols, np.arange(len(cols))] += 1.0 + D * scale * nug / (1.0 + nug)
+    resid = ainv @ a_cols
+    resid[cols, np.arange(len(cols))] -= 1.0
+    print('cfg4 full size: max |A^-1 A - I| on %d sampled columns = %.2e' % (len(cols), np.max(np.abs(resid))))
+    assert np.max(np.abs(resid)) <= 5e-2
+    del ainv, resid, a_cols
+    # float32 vs this build's float64 path at full size
+    m64 = LCGP(y=y, x=x, q=cfg['q'])
+    v64, g64 = m64.loss_and_grad(u)
+    e_v, e_g = abs(v1 - v64) / abs(v64), np.max(np.abs(g1 - g64)) / np.max(np.abs(g64))
+    print('cfg4 full size: fp32 vs fp64 path NLL rel %.2e, gradient / max|g| %.2e' % (e_v, e_g))
+    assert e_v <= NLL_TOL32 and e_g <= GRAD_TOL32

@@ -104,21 +104,28 @@ def test_committed_golden_vectors(name):
 
 
 def test_kat2_fit_predict_on_the_gpu_matches_the_reference_notebook():
+    """The reference's only stored run (illustration-examples/lcgp-rep-1d-illustration.ipynb), driven the way the
+    notebook drives it -- through the example harness (docs/call_model.py) -- on the HIP path, scored with the
+    product's own metrics module (pinned to the reference's evaluation.py by tests/test_evaluation_golden.py)."""
+    from lcgp_amd import evaluation, harness
     xtr, ytr, xte, ytrue = kd.kat_dataset()
-    m = LCGP(y=ytr, x=xtr, q=3, diag_error_structure=[1, 1, 1], robust_mean=True, submethod='rep')
+    run = harness.LCGPRun(runno='kat2', data=dict(xtrain=xtr, ytrain=ytr, xtest=xte, ytest=ytrue, ytrue=ytrue),
+                          submethod='rep', num_latent=3, err_struct=[1, 1, 1], robust=True)
+    run.define_model()
+    m = run.model
     np.testing.assert_allclose(m.diag_D.numpy(), kd.KAT_DIAG_D, atol=5e-9, rtol=0)
     before = float(m.loss())
-    m.fit()
+    run.train()
     assert float(m.loss()) < before
     lLmb, _, ls2, _ = m.get_param()
     np.testing.assert_allclose(lLmb.numpy()[:, 0], kd.KAT_LENGTHSCALES, rtol=1e-3)
     np.testing.assert_allclose(ls2.numpy(), kd.KAT_LSIGMA2S, atol=1e-3)
-    mean, pvar, cvar = (t.numpy() for t in m.predict(xte))
-    assert abs(orc.rmse(ytrue, mean) - kd.KAT_RMSE) < 5e-5
-    assert abs(orc.normalized_rmse(ytrue, mean) - kd.KAT_NRMSE) < 5e-5
-    cover, width = orc.intervalstats(ytrue, mean, cvar)
+    mean, pvar, cvar = run.predict()
+    assert abs(evaluation.rmse(ytrue, mean) - kd.KAT_RMSE) < 5e-5
+    assert abs(evaluation.normalized_rmse(ytrue, mean) - kd.KAT_NRMSE) < 5e-5
+    cover, width = evaluation.intervalstats(ytrue, mean, cvar)
     assert abs(cover - kd.KAT_COVER) < 5e-4 and abs(width - kd.KAT_WIDTH) < 5e-5
-    assert abs(orc.dss_diag(ytrue, mean, cvar) - kd.KAT_DSS) < 2e-4
+    assert abs(evaluation.dss(ytrue, mean, cvar, use_diag=True) - kd.KAT_DSS) < 2e-4
 
 
 def test_matern32_matches_covmat_restatement():

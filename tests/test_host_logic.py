@@ -237,6 +237,30 @@ def test_predict_and_caches_equal_oracle_through_stand_in(mode):
     np.testing.assert_allclose(m.predict(x0)[0].numpy(), o.predict(x0)[0], rtol=1e-8, atol=1e-10)
 
 
+def test_psi_c_value_as_the_reference_verifier_checks_it():
+    """test_verification.py:138-183 (LCGPVerifier step 3): psi_c == phi^T / (exp(-lsigma2s/2) * ybar_std)[:, None]
+    to 1e-10 (relative Frobenius norm), on the verifier's own problem shape (n_unique=50, reps=3, d=2, p=3 = q)."""
+    rng = np.random.default_rng(0)
+    xu = rng.uniform(0, 1, (50, 2))
+    x = np.tile(xu, (3, 1))
+    y = np.vstack([np.sin(2 * np.pi * x[:, 0]), np.cos(2 * np.pi * x[:, 1]), x[:, 0] * x[:, 1]]) \
+        + 0.05 * rng.standard_normal((3, 150))
+    m = patch_engine(LCGP(y=y, x=x, submethod='rep'))
+    assert m.q == int(m.p) == 3
+    m._compute_aux_predictive_quantities_rep()
+    phi = m.phi.numpy()
+    sis = np.exp(-0.5 * m.lsigma2s.numpy()) * m.ybar_std[:, 0].numpy()
+    manual = phi.T / sis[:, None]
+    got = m.psi_c.numpy()
+    assert got.shape == (m.q, int(m.p))
+    assert np.linalg.norm(got - manual) / np.linalg.norm(manual) < 1e-10
+    # q != p: the reference's expression cannot broadcast (it raises there); this build scales per output instead
+    m2 = patch_engine(LCGP(y=y, x=x, q=2, submethod='rep'))
+    m2._compute_aux_predictive_quantities_rep()
+    sis2 = np.exp(-0.5 * m2.lsigma2s.numpy()) * m2.ybar_std[:, 0].numpy()
+    np.testing.assert_allclose(m2.psi_c.numpy(), m2.phi.numpy().T / sis2[None, :], rtol=1e-13)
+
+
 def test_predict_bad_submethod_keyerror_and_cache_reset():
     x, y, _ = _rep_data()
     m = patch_engine(LCGP(y=y, x=x, submethod='rep'))
