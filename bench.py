@@ -38,6 +38,7 @@ def parse():
     ap.add_argument('--q', type=int, default=None, help='override q (debug only: e.g. one rank\'s share of the components)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-stages', action='store_true')
+    ap.add_argument('--predict', type=int, default=2000, help='new inputs of the predict leg (K6); 0 = skip')
     ap.add_argument('--backend', default='nccl', help='process-group backend for --gpus > 1 (nccl = RCCL)')
     return ap.parse_args()
 
@@ -71,6 +72,30 @@ def stage_times(m, reps=3):
         for i, k in enumerate(names):
             acc[k].append(ev[i].elapsed_time(ev[i + 1]))
     return {k: float(np.median(v)) for k, v in acc.items()}
+
+
+def predict_leg(m, n0, reps=5):
+    """K6 (lcgp.py:808-859): latent mean / variance of n0 new inputs from the factorisation in the workspace, timed with
+    HIP events on the launch stream.  Work per call: U_k = X_k W_k^T, W lower triangular: n0 n^2 flops per component."""
+    import torch
+    eng = m._engine
+    rng = np.random.default_rng(7)
+    x0s = rng.uniform(0.0, 1.0, (n0, int(m.d)))
+    st = torch.cuda.current_stream(eng.device)
+    eng.predict_device(x0s)                                  # warm-up (allocates the engine-owned scratch)
+    ts = []
+    for _ in range(reps):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(st)
+        eng.predict_device(x0s)
+        e1.record(st)
+        torch.cuda.synchronize(eng.device)
+        ts.append(e0.elapsed_time(e1))
+    ms = float(np.median(ts))
+    fl = float(eng.q_local) * n0 * float(eng.n) ** 2
+    return dict(n0=n0, ms=ms, flops=fl, tflops=fl / (ms * 1e-3) / 1e12,
+                note='cross covariance + U = X W^T on the MFMA tile kernel + row reductions, all local components per launch; '
+                     'includes the H2D copy of x0')
 
 
 def log(msg):
@@ -243,6 +268,12 @@ def main():
                                    lauum=fl / (st['lauum'] * 1e-3) / 1e12)
         esz = 8 if dtype == 'float64' else 4
         out['build_gbs'] = ql * (n * n / 2.0) * esz / (st['build'] * 1e-3) / 1e9     # lower tiles only are written
+        if args.predict > 0:
+            # (the stage passes above re-ran build / factorisation / inverse at the resident theta_0: L^-1 and z are consistent)
+            pr = predict_leg(m, args.predict)
+            pr['frac_of_mfma_peak'] = pr['tflops'] / peak
+            out['predict'] = pr
+            log('predict leg: n0=%d %.3f ms = %.1f TFLOP/s' % (pr['n0'], pr['ms'], pr['tflops']))
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         log('cpu baseline (bounded sample) ...')

@@ -113,19 +113,46 @@ __device__ __forceinline__ const double* th_row(const double* theta, int d, int 
     return theta + (size_t)k * (d + 3 + p);
 }
 
+// exp(x) for x <= 0 (the kernel's -sum_j S_j): Cody-Waite reduction x = k ln2 + r, degree-13 Taylor polynomial on
+// |r| <= ln2/2 (truncation 4e-18), scaling by v_ldexp_f64.  <= 1 ulp against libm over [-745, 0] (20 M samples on the
+// host); about half the instructions of the library exp, whose overflow / NaN handling cannot occur here -- the
+// kernel build and the gradient contraction are bound by fp64 VALU issue, not by HBM, with the library version.
+__device__ __forceinline__ double exp_nonpos(double x) {
+    const double kf = rint(x * 1.4426950408889634074);
+    double r = fma(-kf, 6.93147180369123816490e-01, x);
+    r = fma(-kf, 1.90821492927058770002e-10, r);
+    double p = 1.6059043836821613e-10;            // 1/13!
+    p = fma(p, r, 2.08767569878681e-09);
+    p = fma(p, r, 2.505210838544172e-08);
+    p = fma(p, r, 2.755731922398589e-07);
+    p = fma(p, r, 2.7557319223985893e-06);
+    p = fma(p, r, 2.48015873015873e-05);
+    p = fma(p, r, 1.984126984126984e-04);
+    p = fma(p, r, 1.388888888888889e-03);
+    p = fma(p, r, 8.333333333333333e-03);
+    p = fma(p, r, 4.1666666666666664e-02);
+    p = fma(p, r, 1.6666666666666666e-01);
+    p = fma(p, r, 0.5);
+    p = fma(p, r, 1.0);
+    p = fma(p, r, 1.0);
+    return ldexp(p, (int)kf);
+}
+// float32 (no reference precision to match): v_exp_f32 on x log2(e); the absolute error stays below 1e-7
+__device__ __forceinline__ float exp_nonpos(float x) { return __expf(x); }
+
 // ---------------------------------------------------------------------------------------------------
 // K1: kernel build.   A_ij = delta_ij + D sr_i sr_j s ((1 - nt) C0_ij + nt delta_ij)
 //   C0 = prod_j (1 + S_j) exp(-sum_j S_j),  S_j = |x_i,j/ell_j - x_i',j/ell_j|      (covmat.py:35-53)
 // One 64x64 lower tile per workgroup; x rows/cols staged in LDS already divided by ell.
 // ---------------------------------------------------------------------------------------------------
-template <typename T>
+template <typename T, int DD /* >= d: the per-dimension loop is unrolled to DD */>
 __global__ __launch_bounds__(256) void build_kernel(T* __restrict__ M, size_t mat, int n, int npad, int d, int p,
                                                     const T* __restrict__ x, const T* __restrict__ sr,
                                                     const double* __restrict__ theta, int ntile,
                                                     const T* __restrict__ Y, T* __restrict__ bvec) {
     // arithmetic in the storage type: the float32 variant is the HBM-bound regime (one float exp per element)
-    __shared__ T xr[TS][DMAX + 1];
-    __shared__ T xc[TS][DMAX + 1];
+    __shared__ T xr[TS][DD + 1];
+    __shared__ T xc[TS][DD + 1];
     __shared__ T srr[TS], src[TS];
     const int k = blockIdx.y;
     if ((int)blockIdx.x >= ntile) {
@@ -156,11 +183,11 @@ __global__ __launch_bounds__(256) void build_kernel(T* __restrict__ M, size_t ma
     const T c_off = (T)(D * scale * (1.0 - nt));        // multiplies C0
     const T c_diag = (T)(1.0 + D * scale * nt);         // extra term on the diagonal (times sr_i^2)
     const int tid = threadIdx.x;
-    for (int e = tid; e < TS * d; e += 256) {
-        int i = e / d, j = e - i * d;
+    for (int e = tid; e < TS * DD; e += 256) {             // (columns d .. DD-1 are zero: they add |0 - 0| = 0)
+        int i = e / DD, j = e - i * DD;
         int gi = r * TS + i, gj = c * TS + i;
-        xr[i][j] = gi < n ? (T)((double)x[(size_t)gi * d + j] / th[j]) : (T)0;
-        xc[i][j] = gj < n ? (T)((double)x[(size_t)gj * d + j] / th[j]) : (T)0;
+        xr[i][j] = (gi < n && j < d) ? (T)((double)x[(size_t)gi * d + j] / th[j]) : (T)0;
+        xc[i][j] = (gj < n && j < d) ? (T)((double)x[(size_t)gj * d + j] / th[j]) : (T)0;
     }
     if (tid < TS) {
         int gi = r * TS + tid, gj = c * TS + tid;
@@ -179,21 +206,20 @@ __global__ __launch_bounds__(256) void build_kernel(T* __restrict__ M, size_t ma
     for (int a = 0; a < 4; ++a)
 #pragma unroll
         for (int b = 0; b < 4; ++b) { poly[a][b] = (T)1; ssum[a][b] = (T)0; }
+    constexpr int UNR = DD <= 6 ? DD : 2;          // (fully unrolled the LDS reads of all dimensions are hoisted: registers)
+#pragma unroll UNR
+    for (int jj = 0; jj < DD; ++jj) {
+        T xa[4], xb[4];
 #pragma unroll
-    for (int jj = 0; jj < DMAX; ++jj) {
-        if (jj < d) {
-            T xa[4], xb[4];
+        for (int a = 0; a < 4; ++a) { xa[a] = xr[i0 + a][jj]; xb[a] = xc[j0 + a][jj]; }
 #pragma unroll
-            for (int a = 0; a < 4; ++a) { xa[a] = xr[i0 + a][jj]; xb[a] = xc[j0 + a][jj]; }
+        for (int a = 0; a < 4; ++a)
 #pragma unroll
-            for (int a = 0; a < 4; ++a)
-#pragma unroll
-                for (int b = 0; b < 4; ++b) {
-                    const T sd = fabs(xa[a] - xb[b]);
-                    poly[a][b] = fma(poly[a][b], sd, poly[a][b]);
-                    ssum[a][b] -= sd;
-                }
-        }
+            for (int b = 0; b < 4; ++b) {
+                const T sd = fabs(xa[a] - xb[b]);
+                poly[a][b] = fma(poly[a][b], sd, poly[a][b]);
+                ssum[a][b] -= sd;
+            }
     }
 #pragma unroll
     for (int a = 0; a < 4; ++a) {
@@ -203,7 +229,7 @@ __global__ __launch_bounds__(256) void build_kernel(T* __restrict__ M, size_t ma
         for (int b = 0; b < 4; ++b) {
             const int gj = c * TS + j0 + b;
             if (gi < n && gj < n) {
-                const T c0 = poly[a][b] * exp(ssum[a][b]);
+                const T c0 = poly[a][b] * exp_nonpos(ssum[a][b]);
                 const T ss = srr[i0 + a] * src[j0 + b];
                 v[b] = ss * c_off * c0;
                 if (gi == gj) v[b] += (T)1 + (c_diag - (T)1) * ss;
@@ -225,13 +251,17 @@ template <typename T>
 __global__ __launch_bounds__(256) void cross_kernel(T* __restrict__ out, int ldo, int n1, int n2, int d,
                                                     const T* __restrict__ x1, const T* __restrict__ x2,
                                                     ThetaArg tv, const double* __restrict__ thp /*ell[d], scale, nug*/,
-                                                    int same, const T* __restrict__ colscale, int n1pad, int n2pad) {
+                                                    int same, const T* __restrict__ colscale, int n1pad, int n2pad,
+                                                    int th_stride /*doubles between the theta rows of components*/,
+                                                    size_t out_stride /*elements between the output slabs*/) {
     __shared__ double xr[TS][DMAX + 1];
     __shared__ double xc[TS][DMAX + 1];
     __shared__ double cs[TS];
     __shared__ double th[DMAX + 2];
     const int r = blockIdx.y, c = blockIdx.x;
     const int tid = threadIdx.x;
+    if (thp) thp += (size_t)blockIdx.z * th_stride;
+    out += (size_t)blockIdx.z * out_stride;
     if (tid < d + 2) th[tid] = thp ? thp[tid] : tv.v[tid];
     __syncthreads();
     const double scale = th[d], nug = th[d + 1];
@@ -261,7 +291,7 @@ __global__ __launch_bounds__(256) void cross_kernel(T* __restrict__ out, int ldo
                 poly *= 1.0 + s;
                 ssum -= s;
             }
-            double c0 = poly * exp(ssum);
+            double c0 = poly * exp_nonpos(ssum);
             double dl = (same && gi + (same - 1) == gj) ? 1.0 : 0.0;   // same = 1 + row offset of x1 within x2
             v = scale * ((1.0 - nt) * c0 + nt * dl) * cs[j];
         }
@@ -614,7 +644,7 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, const int lin /*blo
         Ct = Cb + (size_t)r * TM * g.ldC + (size_t)c * TM;
     } else {
         // OP_PRED_U: U[m, r] = sum_{kt = 0}^{r} X[m, kt] W[r, kt]^T    (X = scaled cross covariance, n0pad x npad)
-        const int r = bid % g.nb, m = bid / g.nb;
+        const int r = g.nb - 1 - bid / g.p0, m = bid % g.p0;       // p0 = row tiles of X; longest k loops (large r) first
         A0 = Ab + (size_t)m * TM * g.ldA; dA = TM;
         B0 = Bb + (size_t)r * TM * g.ldB; dB = TM;
         nkt = r + 1;
@@ -1144,23 +1174,25 @@ __global__ __launch_bounds__(256) void grad_kernel(const T* __restrict__ V, size
         const double ainv = (double)Vk[(size_t)gi * npad + gj];
         const double wgt = gi == gj ? 1.0 : 2.0;
         const double G = wgt * srr[i] * src[j] * (0.5 * D * ainv - 0.5 * zr[i] * zc[j]);
-        double poly = 1.0, ssum = 0.0;
-        double tt[DD];
+        // C0 S_j^2 / (1 + S_j) = exp(-sum S) S_j^2 prod_{i != j} (1 + S_i): prefix / suffix products, no division
+        double sv[DD], pre[DD];
+        double prod = 1.0, ssum = 0.0;
 #pragma unroll
         for (int jj = 0; jj < DD; ++jj) {
-            if (jj < d) {
-                double s = fabs(xr[i][jj] - xc[j][jj]);
-                poly *= 1.0 + s;
-                ssum -= s;
-                tt[jj] = s * s * fast_rcp(1.0 + s);   // (rcp + 2 Newton steps: full double accuracy, 4x fewer instructions than IEEE division)
-            } else {
-                tt[jj] = 0.0;
-            }
+            const double s = jj < d ? fabs(xr[i][jj] - xc[j][jj]) : 0.0;
+            sv[jj] = s;
+            pre[jj] = prod;
+            prod = fma(prod, s, prod);
+            ssum -= s;
         }
-        const double gc0 = G * poly * exp(ssum);
+        const double ge = G * exp_nonpos(ssum);
+        double suf = 1.0;
 #pragma unroll
-        for (int jj = 0; jj < DD; ++jj) acc[jj] += gc0 * tt[jj];
-        acc[DD] += gc0;
+        for (int jj = DD - 1; jj >= 0; --jj) {
+            acc[jj] = fma(ge * (sv[jj] * sv[jj]), pre[jj] * suf, acc[jj]);
+            suf = fma(suf, sv[jj], suf);
+        }
+        acc[DD] = fma(ge, prod, acc[DD]);
         if (gi == gj) acc[DD + 1] += G;
     }
     // deterministic block reduction: wave butterfly, then 4 waves through LDS
@@ -1269,21 +1301,26 @@ __global__ void fetch_kernel(const T* __restrict__ src, int npad, int n, T* __re
     dst[(size_t)i * n + j] = j <= i ? src[(size_t)i * npad + j] : src[(size_t)j * npad + i];
 }
 
-// ghat[m] = sum_i X[m, i] z_i ;  gvar[m] = scale - D * sum_i U[m, i]^2        (one wave per row m)
+// ghat[k, m] = sum_i X_k[m, i] z_k[i] ;  gvar[k, m] = scale_k - D_k * sum_i U_k[m, i]^2        (one wave per row m)
 template <typename T>
-__global__ __launch_bounds__(64) void pred_reduce_kernel(const T* __restrict__ X, const T* __restrict__ U, int ld, int n,
-                                                         const T* __restrict__ z, const double* __restrict__ th, int d,
+__global__ __launch_bounds__(64) void pred_reduce_kernel(const T* __restrict__ X, const T* __restrict__ U, size_t slab, int ld,
+                                                         int n, const T* __restrict__ z, int npad,
+                                                         const double* __restrict__ theta, int tw, int d, int n0,
                                                          double* __restrict__ ghat, double* __restrict__ gvar) {
-    const int m = blockIdx.x, lane = threadIdx.x;
+    const int m = blockIdx.x, k = blockIdx.y, lane = threadIdx.x;
+    const double* th = theta + (size_t)k * tw;
     const double scale = th[d], D = th[d + 2];
+    const T* Xr = X + (size_t)k * slab + (size_t)m * ld;
+    const T* Ur = U + (size_t)k * slab + (size_t)m * ld;
+    const T* zk = z + (size_t)k * npad;
     double s1 = 0.0, s2 = 0.0;
     for (int i = lane; i < n; i += 64) {
-        double u = (double)U[(size_t)m * ld + i];
-        s1 += (double)X[(size_t)m * ld + i] * (double)z[i];
+        const double u = (double)Ur[i];
+        s1 += (double)Xr[i] * (double)zk[i];
         s2 += u * u;
     }
     for (int off = 32; off > 0; off >>= 1) { s1 += __shfl_xor(s1, off); s2 += __shfl_xor(s2, off); }
-    if (lane == 0) { ghat[m] = s1; gvar[m] = scale - D * s2; }
+    if (lane == 0) { ghat[(size_t)k * n0 + m] = s1; gvar[(size_t)k * n0 + m] = scale - D * s2; }
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -1295,12 +1332,21 @@ __global__ __launch_bounds__(64) void pred_reduce_kernel(const T* __restrict__ X
         if (e__ != hipSuccess) return fail(what, e__);      \
     } while (0)
 
+template <typename T, int DD>
+void launch_build(hipStream_t st, const Ws& w, dim3 grid, const void* x, const void* sr, const double* theta, const void* Y) {
+    hipLaunchKernelGGL((build_kernel<T, DD>), grid, dim3(256), 0, st, (T*)(w.base + w.off_M), w.mat, w.n, w.npad, w.d, w.p,
+                       (const T*)x, (const T*)sr, theta, w.ntile_lower, (const T*)Y, (T*)(w.base + w.off_b));
+}
+
 template <typename T>
 int do_build(hipStream_t st, const Ws& w, const void* x, const void* sr, const double* theta, const void* Y = nullptr) {
     // with Y the launch also computes b_k = Y^T psi_k into the workspace (extra blocks past the tiles)
     dim3 grid(w.ntile_lower + (Y ? (w.npad + 255) / 256 : 0), w.q);
-    hipLaunchKernelGGL((build_kernel<T>), grid, dim3(256), 0, st, (T*)(w.base + w.off_M), w.mat, w.n, w.npad, w.d, w.p,
-                       (const T*)x, (const T*)sr, theta, w.ntile_lower, (const T*)Y, (T*)(w.base + w.off_b));
+    if (w.d <= 2) launch_build<T, 2>(st, w, grid, x, sr, theta, Y);
+    else if (w.d <= 4) launch_build<T, 4>(st, w, grid, x, sr, theta, Y);
+    else if (w.d <= 6) launch_build<T, 6>(st, w, grid, x, sr, theta, Y);
+    else if (w.d <= 10) launch_build<T, 10>(st, w, grid, x, sr, theta, Y);
+    else launch_build<T, DMAX>(st, w, grid, x, sr, theta, Y);
     CHECK_LAUNCH("build_kernel");
     return 0;
 }
@@ -1692,35 +1738,46 @@ int do_matern(hipStream_t st, int n1, int n2, int d, const void* x1, const void*
               void* out) {
     dim3 grid((n2 + TS - 1) / TS, (n1 + TS - 1) / TS);
     hipLaunchKernelGGL((cross_kernel<T>), grid, dim3(256), 0, st, (T*)out, n2, n1, n2, d, (const T*)x1, (const T*)x2, th,
-                       (const double*)nullptr, same, (const T*)nullptr, n1, n2);
+                       (const double*)nullptr, same, (const T*)nullptr, n1, n2, 0, (size_t)0);
     CHECK_LAUNCH("cross_kernel");
     return 0;
 }
 
+// rows of the padded cross-covariance block: whole 128-tiles when there are at least 128 new inputs (the MFMA products
+// then run on the 128x128 8-wave tile kernel), whole 64-tiles otherwise
+inline int predict_pad(int n0) { return n0 >= 128 ? round_up(n0, 2 * TS) : round_up(n0, TS); }
+
+// K6, all local components in every launch:  X_k = c0k o sr^T (one launch), U_k = X_k W_k^T (one launch of the tile
+// kernel, k tiles only up to the diagonal: W is lower triangular), then the row reductions.
 template <typename T>
 int do_predict(hipStream_t st, const Ws& w, const void* x, const void* sr, const double* theta, int n0, const void* x0,
                int same, void* scratch, double* ghat, double* gvar) {
-    const int n0pad = round_up(n0, TS);
-    T* X = (T*)scratch;  // (w.npad is a multiple of 128)                                   // n0pad x npad : c0k o sr^T (zero padded)
-    T* U = X + (size_t)n0pad * w.npad;                    // n0pad x npad : X W^T = (L^-1 X^T)^T
+    const int n0pad = predict_pad(n0);
+    const size_t slab = (size_t)n0pad * w.npad;
+    T* X = (T*)scratch;                 // q slabs n0pad x npad : c0k o sr^T (zero padded)
+    T* U = X + slab * w.q;              // q slabs n0pad x npad : X W^T = (L^-1 X^T)^T
+    const int tw = w.d + 3 + w.p;
     ThetaArg dummy;
     memset(&dummy, 0, sizeof(dummy));
-    for (int k = 0; k < w.q; ++k) {
-        const double* th = theta + (size_t)k * (w.d + 3 + w.p);
-        dim3 grid(w.nb, n0pad / TS);
-        hipLaunchKernelGGL((cross_kernel<T>), grid, dim3(256), 0, st, X, w.npad, n0, w.n, w.d, (const T*)x0, (const T*)x,
-                           dummy, th, same, (const T*)sr, n0pad, w.npad);
-        CHECK_LAUNCH("cross_kernel");
-        GemmArgs g;
-        g.A = X; g.B = (const T*)(w.base + w.off_W) + (size_t)k * w.mat; g.C = U;
-        g.sA = g.sB = g.sC = 0; g.ldA = g.ldB = g.ldC = w.npad; g.nb = w.nb; g.p0 = g.p1 = g.p2 = g.p3 = 0;
-        int rc = launch_gemm<T, OP_PRED_U>(st, g, (n0pad / TS) * w.nb, 1);
-        if (rc) return rc;
-        hipLaunchKernelGGL((pred_reduce_kernel<T>), dim3(n0), dim3(64), 0, st, (const T*)X, (const T*)U, w.npad, w.n,
-                           (const T*)(w.base + w.off_z) + (size_t)k * w.npad, th, w.d, ghat + (size_t)k * n0,
-                           gvar + (size_t)k * n0);
-        CHECK_LAUNCH("pred_reduce_kernel");
+    dim3 grid(w.nb, n0pad / TS, w.q);
+    hipLaunchKernelGGL((cross_kernel<T>), grid, dim3(256), 0, st, X, w.npad, n0, w.n, w.d, (const T*)x0, (const T*)x, dummy,
+                       theta, same, (const T*)sr, n0pad, w.npad, tw, slab);
+    CHECK_LAUNCH("cross_kernel");
+    GemmArgs g;
+    g.A = X; g.B = (const T*)(w.base + w.off_W); g.C = U;
+    g.sA = slab; g.sB = w.mat; g.sC = slab; g.ldA = g.ldB = g.ldC = w.npad; g.p1 = g.p2 = g.p3 = 0;
+    int rc;
+    if (n0pad % (2 * TS) == 0) {
+        g.nb = w.nb / 2; g.p0 = n0pad / (2 * TS);
+        rc = launch_gemm<T, OP_PRED_U, 128>(st, g, g.p0 * g.nb, w.q);
+    } else {
+        g.nb = w.nb; g.p0 = n0pad / TS;
+        rc = launch_gemm<T, OP_PRED_U, 64>(st, g, g.p0 * g.nb, w.q);
     }
+    if (rc) return rc;
+    hipLaunchKernelGGL((pred_reduce_kernel<T>), dim3(n0, w.q), dim3(64), 0, st, (const T*)X, (const T*)U, slab, w.npad, w.n,
+                       (const T*)(w.base + w.off_z), w.npad, theta, tw, w.d, n0, ghat, gvar);
+    CHECK_LAUNCH("pred_reduce_kernel");
     return 0;
 }
 
@@ -1760,8 +1817,8 @@ int lcgp_predict_scratch_bytes(int dtype, int n, int q_local, int n0, size_t* by
     if (dtype != LCGP_F64 && dtype != LCGP_F32) return bad("dtype must be 0 (f64) or 1 (f32)");
     if (n < 1 || n0 < 1 || q_local < 1) return bad("n, n0, q_local must be >= 1");
     if (!bytes) return bad("bytes is NULL");
-    const size_t npad = round_up(n, 2 * TS), n0pad = round_up(n0, TS);
-    *bytes = 2 * n0pad * npad * (dtype == LCGP_F64 ? 8 : 4);
+    const size_t npad = round_up(n, 2 * TS), n0pad = predict_pad(n0);
+    *bytes = 2 * (size_t)q_local * n0pad * npad * (dtype == LCGP_F64 ? 8 : 4);
     return 0;
 }
 
