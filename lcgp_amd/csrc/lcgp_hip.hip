@@ -197,10 +197,14 @@ __global__ __launch_bounds__(256) void build_kernel(T* __restrict__ M, size_t ma
     __syncthreads();
     T* Mk = M + (size_t)k * mat;
     // 4 x 4 elements per thread (16 x 16 threads per tile): every LDS read of a scaled input row/column is used four
-    // times, 16 independent exp chains per thread, and each thread stores four 4-element row segments (a wave writes
-    // whole 512-byte row pieces in fp64)
+    // times, 16 independent exp chains per thread.  Columns per thread: in fp32 four consecutive ones (one 16-byte store
+    // per row; the 16 lanes of a row write 256 contiguous bytes); in fp64 the pairs {2 tx, 2 tx + 1} and {32 + 2 tx, 33 + 2 tx},
+    // so that EACH 16-byte store instruction of the 16 lanes covers 256 contiguous bytes (with four consecutive columns
+    // per thread every instruction would write 16 of each 32 bytes: two partial passes over every line)
     const int tx = tid & 15, ty = tid >> 4;
-    const int i0 = ty * 4, j0 = tx * 4;
+    const int i0 = ty * 4;
+    constexpr bool PAIRS = sizeof(T) == 8;
+    auto colof = [&](int b) { return PAIRS ? (b >> 1) * 32 + 2 * tx + (b & 1) : 4 * tx + b; };
     T poly[4][4], ssum[4][4];
 #pragma unroll
     for (int a = 0; a < 4; ++a)
@@ -211,7 +215,7 @@ __global__ __launch_bounds__(256) void build_kernel(T* __restrict__ M, size_t ma
     for (int jj = 0; jj < DD; ++jj) {
         T xa[4], xb[4];
 #pragma unroll
-        for (int a = 0; a < 4; ++a) { xa[a] = xr[i0 + a][jj]; xb[a] = xc[j0 + a][jj]; }
+        for (int a = 0; a < 4; ++a) { xa[a] = xr[i0 + a][jj]; xb[a] = xc[colof(a)][jj]; }
 #pragma unroll
         for (int a = 0; a < 4; ++a)
 #pragma unroll
@@ -227,19 +231,25 @@ __global__ __launch_bounds__(256) void build_kernel(T* __restrict__ M, size_t ma
         T v[4];
 #pragma unroll
         for (int b = 0; b < 4; ++b) {
-            const int gj = c * TS + j0 + b;
+            const int gj = c * TS + colof(b);
             if (gi < n && gj < n) {
                 const T c0 = poly[a][b] * exp_nonpos(ssum[a][b]);
-                const T ss = srr[i0 + a] * src[j0 + b];
+                const T ss = srr[i0 + a] * src[colof(b)];
                 v[b] = ss * c_off * c0;
                 if (gi == gj) v[b] += (T)1 + (c_diag - (T)1) * ss;
             } else {
                 v[b] = gi == gj ? (T)1 : (T)0;
             }
         }
-        T* dst = Mk + (size_t)gi * npad + c * TS + j0;
-#pragma unroll
-        for (int b = 0; b < 4; ++b) dst[b] = v[b];
+        T* dst = Mk + (size_t)gi * npad + c * TS;
+        if constexpr (PAIRS) {
+            typedef T pair_t __attribute__((ext_vector_type(2)));
+            *(pair_t*)(dst + colof(0)) = pair_t{v[0], v[1]};
+            *(pair_t*)(dst + colof(2)) = pair_t{v[2], v[3]};
+        } else {
+            typedef T quad_t __attribute__((ext_vector_type(4)));
+            *(quad_t*)(dst + colof(0)) = quad_t{v[0], v[1], v[2], v[3]};
+        }
     }
 }
 
@@ -1165,35 +1175,43 @@ __global__ __launch_bounds__(256) void grad_kernel(const T* __restrict__ V, size
 #pragma unroll
     for (int e = 0; e < DD + 2; ++e) acc[e] = 0.0;
     const T* Vk = V + (size_t)k * mat;
-    const int j = tid & 63;
-    const int gj = c * TS + j;
-    for (int m = 0; m < 16; ++m) {
-        const int i = (tid >> 6) * 16 + m;
+    // thread = two adjacent columns (one 16-byte load per row in fp64) x 8 rows: two independent chains per load
+    const int j0 = (tid & 31) * 2;
+    typedef T pair_t __attribute__((ext_vector_type(2)));
+    for (int m = 0; m < 8; ++m) {
+        const int i = (tid >> 5) * 8 + m;
         const int gi = r * TS + i;
-        if (gi >= n || gj >= n || gj > gi) continue;
-        const double ainv = (double)Vk[(size_t)gi * npad + gj];
-        const double wgt = gi == gj ? 1.0 : 2.0;
-        const double G = wgt * srr[i] * src[j] * (0.5 * D * ainv - 0.5 * zr[i] * zc[j]);
-        // C0 S_j^2 / (1 + S_j) = exp(-sum S) S_j^2 prod_{i != j} (1 + S_i): prefix / suffix products, no division
-        double sv[DD], pre[DD];
-        double prod = 1.0, ssum = 0.0;
+        if (gi >= n) continue;
+        const pair_t av = *(const pair_t*)(Vk + (size_t)gi * npad + c * TS + j0);
 #pragma unroll
-        for (int jj = 0; jj < DD; ++jj) {
-            const double s = jj < d ? fabs(xr[i][jj] - xc[j][jj]) : 0.0;
-            sv[jj] = s;
-            pre[jj] = prod;
-            prod = fma(prod, s, prod);
-            ssum -= s;
-        }
-        const double ge = G * exp_nonpos(ssum);
-        double suf = 1.0;
+        for (int h = 0; h < 2; ++h) {
+            const int j = j0 + h;
+            const int gj = c * TS + j;
+            if (gj >= n || gj > gi) continue;
+            const double ainv = (double)av[h];
+            const double wgt = gi == gj ? 1.0 : 2.0;
+            const double G = wgt * srr[i] * src[j] * (0.5 * D * ainv - 0.5 * zr[i] * zc[j]);
+            // C0 S_j^2 / (1 + S_j) = exp(-sum S) S_j^2 prod_{i != j} (1 + S_i): prefix / suffix products, no division
+            double sv[DD], pre[DD];
+            double prod = 1.0, ssum = 0.0;
 #pragma unroll
-        for (int jj = DD - 1; jj >= 0; --jj) {
-            acc[jj] = fma(ge * (sv[jj] * sv[jj]), pre[jj] * suf, acc[jj]);
-            suf = fma(suf, sv[jj], suf);
+            for (int jj = 0; jj < DD; ++jj) {
+                const double s = jj < d ? fabs(xr[i][jj] - xc[j][jj]) : 0.0;
+                sv[jj] = s;
+                pre[jj] = prod;
+                prod = fma(prod, s, prod);
+                ssum -= s;
+            }
+            const double ge = G * exp_nonpos(ssum);
+            double suf = 1.0;
+#pragma unroll
+            for (int jj = DD - 1; jj >= 0; --jj) {
+                acc[jj] = fma(ge * (sv[jj] * sv[jj]), pre[jj] * suf, acc[jj]);
+                suf = fma(suf, sv[jj], suf);
+            }
+            acc[DD] = fma(ge, prod, acc[DD]);
+            if (gi == gj) acc[DD + 1] += G;
         }
-        acc[DD] = fma(ge, prod, acc[DD]);
-        if (gi == gj) acc[DD + 1] += G;
     }
     // deterministic block reduction: wave butterfly, then 4 waves through LDS
 #pragma unroll
