@@ -57,6 +57,14 @@ def main():
     assert abs(v1 - v2) <= 1e-12 * abs(v2)
     np.testing.assert_allclose(g1, g2, rtol=1e-10, atol=1e-13)
     np.testing.assert_allclose(m.predict(x[:5])[0].numpy(), o.predict(x[:5])[0], rtol=1e-7, atol=1e-9)
+    # the cache views are gathers too: the rank WITHOUT a component (and without an engine) must enter them as well,
+    # or the other rank would wait in the collective forever
+    cinv = m.CinvMs.numpy()
+    ths = m.Ths.numpy()
+    assert cinv.shape == (1, 30) and ths.shape == (1, 30, 30) and np.all(np.isfinite(cinv)) and np.all(np.isfinite(ths))
+    both = [None, None]
+    dist.all_gather_object(both, cinv.tobytes())
+    assert both[0] == both[1]
     dist.barrier()
     dist.destroy_process_group()
     print("RANK %d OK" % rank)

@@ -1,0 +1,36 @@
+#!/bin/bash
+# Runs on the GPU box (gpurun): the measurements DESIGN.md / profiles/ quote for one round.
+#   tools/profile_round.sh <tag>        -> gpurun_out/<tag>/...
+# rocprofv3 passes: --kernel-trace --stats on its own; every --pmc pass on its own with --kernel-trace only
+# (never together with the hip/hsa/memory trace domains); the program itself follows `--`.
+set -u
+TAG=${1:-r02}
+ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+OUT=$ROOT/gpurun_out/$TAG
+mkdir -p "$OUT"
+cd /tmp && export TMPDIR=/tmp
+step() { echo "[profile_round] $*"; }
+
+step "bench (default: N=1, headline configuration)"
+python3 $ROOT/bench.py > $OUT/bench.json 2> $OUT/bench.err || exit 1
+step "bench, other configurations"
+for c in 2 4 5; do python3 $ROOT/bench.py --config $c --steps 6 --warmup 2 > $OUT/bench_cfg$c.json 2> $OUT/bench_cfg$c.err || exit 1; done
+step "bench, one rank's share of the headline configuration (q_local = 4, 2, 1)"
+for q in 4 2 1; do python3 $ROOT/bench.py --q $q --steps 12 --warmup 3 --no-cpu-baseline > $OUT/bench_q$q.json 2> $OUT/bench_q$q.err || exit 1; done
+step "host overhead"
+python3 $ROOT/tools/host_overhead.py 3 > $OUT/host_overhead.txt 2>&1 || exit 1
+step "kernel stats of the bench command"
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $ROOT/bench.py --steps 10 --warmup 2 --no-cpu-baseline > $OUT/stats.log 2>&1 || exit 1
+step "PMC: VALU / occupancy counters (cfg3, 3 evaluations)"
+rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY --output-format csv -d $OUT/pmc_valu -- python3 $ROOT/tools/run_evals.py 3 0 3 > $OUT/pmc_valu.log 2>&1 || exit 1
+step "PMC: the same counters, cfg4 (float32, n=16384), 1 evaluation"
+rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY --output-format csv -d $OUT/pmc_valu_cfg4 -- python3 $ROOT/tools/run_evals.py 4 0 1 > $OUT/pmc_valu_cfg4.log 2>&1 || exit 1
+step "PMC: FETCH_SIZE"
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 $ROOT/tools/run_evals.py 3 0 3 > $OUT/pmc_fetch.log 2>&1 || exit 1
+step "PMC: WRITE_SIZE"
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 $ROOT/tools/run_evals.py 3 0 3 > $OUT/pmc_write.log 2>&1 || exit 1
+step "PMC: MFMA busy"
+rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F64 GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_mfma -- python3 $ROOT/tools/run_evals.py 3 0 3 > $OUT/pmc_mfma.log 2>&1 || exit 1
+step "two ranks on this one GPU over gloo (rehearsal of the N > 1 launch line; RCCL needs one GPU per rank)"
+cd $ROOT && python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 2 --steps 6 --warmup 2 --backend gloo --no-cpu-baseline > $OUT/bench_gloo2.json 2> $OUT/bench_gloo2.err || exit 1
+step done
