@@ -117,22 +117,29 @@ __device__ __forceinline__ const double* th_row(const double* theta, int d, int 
 // |r| <= ln2/2 (truncation 4e-18), scaling by v_ldexp_f64.  <= 1 ulp against libm over [-745, 0] (20 M samples on the
 // host); about half the instructions of the library exp, whose overflow / NaN handling cannot occur here -- the
 // kernel build and the gradient contraction are bound by fp64 VALU issue, not by HBM, with the library version.
+// p * r + c with the constant c held in a SCALAR register pair: as a literal the compiler re-materialises every 64-bit
+// constant with two v_mov per use (a quarter of the kernel-build instructions, which is bound by VALU issue)
+__device__ __forceinline__ double fma_sc(double p, double r, double c) {
+    double o;
+    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(o) : "v"(p), "v"(r), "s"(c));
+    return o;
+}
+
 __device__ __forceinline__ double exp_nonpos(double x) {
     const double kf = rint(x * 1.4426950408889634074);
     double r = fma(-kf, 6.93147180369123816490e-01, x);
     r = fma(-kf, 1.90821492927058770002e-10, r);
-    double p = 1.6059043836821613e-10;            // 1/13!
-    p = fma(p, r, 2.08767569878681e-09);
-    p = fma(p, r, 2.505210838544172e-08);
-    p = fma(p, r, 2.755731922398589e-07);
-    p = fma(p, r, 2.7557319223985893e-06);
-    p = fma(p, r, 2.48015873015873e-05);
-    p = fma(p, r, 1.984126984126984e-04);
-    p = fma(p, r, 1.388888888888889e-03);
-    p = fma(p, r, 8.333333333333333e-03);
-    p = fma(p, r, 4.1666666666666664e-02);
-    p = fma(p, r, 1.6666666666666666e-01);
-    p = fma(p, r, 0.5);
+    double p = fma_sc(1.6059043836821613e-10, r, 2.08767569878681e-09);     // 1/13!, 1/12!
+    p = fma_sc(p, r, 2.505210838544172e-08);
+    p = fma_sc(p, r, 2.755731922398589e-07);
+    p = fma_sc(p, r, 2.7557319223985893e-06);
+    p = fma_sc(p, r, 2.48015873015873e-05);
+    p = fma_sc(p, r, 1.984126984126984e-04);
+    p = fma_sc(p, r, 1.388888888888889e-03);
+    p = fma_sc(p, r, 8.333333333333333e-03);
+    p = fma_sc(p, r, 4.1666666666666664e-02);
+    p = fma_sc(p, r, 1.6666666666666666e-01);
+    p = fma_sc(p, r, 0.5);
     p = fma(p, r, 1.0);
     p = fma(p, r, 1.0);
     return ldexp(p, (int)kf);
