@@ -25,7 +25,7 @@ namespace {
 
 constexpr int TS = 64;    // tile size (rows/cols of one tile)
 constexpr int KT = 16;    // k extent of one LDS stage
-constexpr int DMAX = 16;  // max input dimension handled by the fused kernels
+constexpr int DMAX = 32;  // max input dimension handled by the fused kernels (instantiated for 2, 4, 6, 10, 16, 32)
 
 typedef double d4 __attribute__((ext_vector_type(4)));
 typedef float f4 __attribute__((ext_vector_type(4)));
@@ -1371,6 +1371,7 @@ int do_build(hipStream_t st, const Ws& w, const void* x, const void* sr, const d
     else if (w.d <= 4) launch_build<T, 4>(st, w, grid, x, sr, theta, Y);
     else if (w.d <= 6) launch_build<T, 6>(st, w, grid, x, sr, theta, Y);
     else if (w.d <= 10) launch_build<T, 10>(st, w, grid, x, sr, theta, Y);
+    else if (w.d <= 16) launch_build<T, 16>(st, w, grid, x, sr, theta, Y);
     else launch_build<T, DMAX>(st, w, grid, x, sr, theta, Y);
     CHECK_LAUNCH("build_kernel");
     return 0;
@@ -1693,6 +1694,7 @@ int do_nll_grad(hipStream_t st, const Ws& w, const lcgp_sched& sc, const void* x
     else if (w.d <= 4) launch_grad<T, 4>(st, w, x, sr, theta);
     else if (w.d <= 6) launch_grad<T, 6>(st, w, x, sr, theta);
     else if (w.d <= 10) launch_grad<T, 10>(st, w, x, sr, theta);
+    else if (w.d <= 16) launch_grad<T, 16>(st, w, x, sr, theta);
     else launch_grad<T, DMAX>(st, w, x, sr, theta);
     CHECK_LAUNCH("grad_kernel");
     hipLaunchKernelGGL((finalize_kernel<T>), dim3(w.q), dim3(256), 0, st, w.n, w.npad, w.d, w.p, w.ntile_lower,
@@ -1747,7 +1749,7 @@ __global__ __launch_bounds__(256) void pack_partial_kernel(int d, int p, int q_l
 int check_common(int dtype, int n, int d, int p, int q) {
     if (dtype != LCGP_F64 && dtype != LCGP_F32) return bad("dtype must be 0 (f64) or 1 (f32)");
     if (n < 1) return bad("n < 1");
-    if (d < 1 || d > DMAX) return bad("d must be in [1, 16]");
+    if (d < 1 || d > DMAX) return bad("d must be in [1, 32]");
     if (p < 1) return bad("p < 1");
     if (q < 1 || q > 65535) return bad("q_local must be in [1, 65535]");
     return 0;
@@ -1851,7 +1853,7 @@ int lcgp_matern32(void* stream, int dtype, int n1, int n2, int d, const void* x1
                   double scale, double nug, int same, void* out) {
     if (dtype != LCGP_F64 && dtype != LCGP_F32) return bad("dtype must be 0 (f64) or 1 (f32)");
     if (n1 < 1 || n2 < 1) return bad("n1/n2 < 1");
-    if (d < 1 || d > DMAX) return bad("d must be in [1, 16]");
+    if (d < 1 || d > DMAX) return bad("d must be in [1, 32]");
     if (!x1 || !x2 || !ell || !out) return bad("NULL pointer");
     ThetaArg th;
     memset(&th, 0, sizeof(th));
@@ -1970,7 +1972,7 @@ int lcgp_nll_grad(void* stream, int dtype, int n, int d, int p, int q_local, con
 
 int lcgp_pack_partial(void* stream, int d, int p, int q_local, int q_total, const int* comp, const double* theta,
                       const double* out, double* vec) {
-    if (d < 1 || d > DMAX || p < 1) return bad("d must be in [1, 16], p >= 1");
+    if (d < 1 || d > DMAX || p < 1) return bad("d must be in [1, 32], p >= 1");
     if (q_local < 0 || q_total < 1 || q_local > q_total) return bad("need 0 <= q_local <= q_total, q_total >= 1");
     if (!vec || (q_local > 0 && (!comp || !theta || !out))) return bad("NULL pointer");
     hipLaunchKernelGGL(pack_partial_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, d, p, q_local, q_total, comp, theta,

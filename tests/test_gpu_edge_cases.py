@@ -33,15 +33,21 @@ def test_tiny_and_tile_boundary_sizes(n, d, p, q):
     assert out[0].shape == (p, 1) and np.all(np.isfinite(out[0].numpy()))
 
 
-def test_maximum_input_dimension_and_refusal_above_it():
-    x, y = synth.make_full(316, 90, 16, 3, 2)
+@pytest.mark.parametrize('seed,d', [(316, 16), (317, 17), (318, 32)])
+def test_wide_input_dimensions(seed, d):
+    """the fused kernels are instantiated for d <= 2, 4, 6, 10, 16, 32: the last two against the oracle"""
+    x, y = synth.make_full(seed, 90, d, 3, 2)
     m = LCGP(y=y, x=x, q=2)
     o = orc.OracleLCGP(y=y, x=x, q=2)
-    _same(m, o, synth.param_points(316, o.get_unconstrained())[1])
-    x17, y17 = synth.make_full(317, 40, 17, 2, 2)
-    m17 = LCGP(y=y17, x=x17, q=2)
+    _same(m, o, synth.param_points(seed, o.get_unconstrained())[1])
+    np.testing.assert_allclose(m.predict(x[:5])[0].numpy(), o.predict(x[:5])[0], rtol=1e-7, atol=1e-9)
+
+
+def test_refusal_above_the_maximum_input_dimension():
+    x33, y33 = synth.make_full(319, 40, 33, 2, 2)
+    m33 = LCGP(y=y33, x=x33, q=2)
     with pytest.raises(RuntimeError, match='d must be'):
-        m17.loss()
+        m33.loss()
 
 
 def test_duplicated_inputs_in_full_mode():
