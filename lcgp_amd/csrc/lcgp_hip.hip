@@ -360,13 +360,60 @@ __device__ __forceinline__ double fast_rsqrt(double a) {
 }
 
 constexpr int LEAF_LDT = TS + 1;
-constexpr int LEAF_SCR = 4 * TS * 17;                                     // per-wave [64][17] transposition scratch
-constexpr int LEAF_W_DOUBLES = LEAF_SCR > TS * LEAF_LDT ? LEAF_SCR : TS * LEAF_LDT;
-constexpr int LEAF_LDS_BYTES = (TS * LEAF_LDT + LEAF_W_DOUBLES + 2 * TS) * 8 + 16;   // lt + w/scratch + dinv + pivs + bad
+constexpr int LEAF_SCR = TS * 17;                                         // ONE [64][17] transposition scratch: only one wave factors at a time
+constexpr int LEAF_LDS_BYTES = (2 * TS * LEAF_LDT + LEAF_SCR + 2 * TS) * 8 + 16;    // lt + w + scratch + dinv + pivs + bad
 
+// Inverse of the lower-triangular 64x64 block, one 16-row block ROW at a time, by ONE wave (no workgroup barrier inside):
+//   W_aa by substitution (lanes 0..15: one column each, solve L_aa w = e_c), then for b < a
+//   T_ab = sum_{m=b}^{a-1} L_am W_mb ;  W_ab = -W_aa T_ab   on the fp64 MFMA.  The accumulator of T (lane: col = l & 15,
+//   rows (l >> 4) + 4 reg) is exactly the B-operand fragment of the second product (k = 4 step + (l >> 4)).
+// Needs L rows of block a and the rows < a of W: row a of the inverse can be formed as soon as panel a is factored.
+__device__ __forceinline__ void leaf_inverse_diag(double (*lt)[LEAF_LDT], double (*w)[LEAF_LDT], const double* dinv, int a,
+                                                  int lane) {
+    if (lane < 16) {
+        const int b0 = a * 16, cl = lane;
+        double wc[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            double sacc = i == cl ? -1.0 : 0.0;
+#pragma unroll
+            for (int m = 0; m < i; ++m) sacc = fma(lt[b0 + m][b0 + i], wc[m], sacc);
+            wc[i] = -sacc * dinv[b0 + i];
+        }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) w[b0 + i][b0 + cl] = wc[i];
+    }
+}
+
+__device__ __forceinline__ d4 leaf_inverse_t(double (*lt)[LEAF_LDT], double (*w)[LEAF_LDT], int a, int b, int lane) {
+    const int li = lane & 15, lq = lane >> 4;
+    d4 tacc = {0.0, 0.0, 0.0, 0.0};
+    for (int mb = b; mb < a; ++mb) {
+#pragma unroll
+        for (int st = 0; st < 4; ++st)
+            tacc = __builtin_amdgcn_mfma_f64_16x16x4f64(lt[mb * 16 + 4 * st + lq][a * 16 + li], w[mb * 16 + 4 * st + lq][b * 16 + li],
+                                                        tacc, 0, 0, 0);
+    }
+    return tacc;
+}
+
+__device__ __forceinline__ void leaf_inverse_w(double (*w)[LEAF_LDT], const d4& tacc, int a, int b, int lane) {
+    const int li = lane & 15, lq = lane >> 4;
+    d4 wacc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int st = 0; st < 4; ++st)
+        wacc = __builtin_amdgcn_mfma_f64_16x16x4f64(w[a * 16 + li][a * 16 + 4 * st + lq], tacc[st], wacc, 0, 0, 0);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) w[a * 16 + lq + 4 * e][b * 16 + li] = -wacc[e];
+}
+
+// Factor AND inverse of the diagonal block.  While wave kb factors its 16-column panel (the 16-pivot chain, alone on its
+// SIMD), wave kb-1 -- idle otherwise -- forms row kb-1 of the inverse from the panels that are already final; only row 3
+// is left when the last panel is done, and that one is spread over all four waves.
 template <typename T>
-__device__ __forceinline__ void leaf_factor_panels(const T* __restrict__ Mb, int npad, double (*lt)[LEAF_LDT],
-                                                   double* scratch, double* dinv, double* pivs, int* bad, int jb) {
+__device__ __forceinline__ void leaf_factor_invert(const T* __restrict__ Mb, int npad, double (*lt)[LEAF_LDT],
+                                                   double (*w)[LEAF_LDT], double* scratch, double* dinv, double* pivs,
+                                                   int* bad, int jb) {
     const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 15, lq = lane >> 4;
     d4 acc[4];
@@ -375,7 +422,7 @@ __device__ __forceinline__ void leaf_factor_panels(const T* __restrict__ Mb, int
 #pragma unroll
         for (int e = 0; e < 4; ++e)
             acc[rb][e] = rb >= wv ? (double)Mb[(size_t)(rb * 16 + lq + 4 * e) * npad + wv * 16 + li] : 0.0;
-    double (*S)[17] = (double (*)[17])(scratch + wv * TS * 17);
+    double (*S)[17] = (double (*)[17])scratch;
     int first_bad = 0;
 #pragma unroll 1
     for (int kb = 0; kb < 4; ++kb) {
@@ -408,6 +455,14 @@ __device__ __forceinline__ void leaf_factor_panels(const T* __restrict__ Mb, int
 #pragma unroll
             for (int m = 0; m < 16; ++m) lt[kb * 16 + m][lane] = lane >= kb * 16 + m ? r[m] : 0.0;
             if (lane == 0) bad[kb] = first_bad;
+        } else if (wv == kb - 1) {
+            // row kb-1 of the inverse (panel kb-1 and everything it needs became visible at the last barrier)
+            const int a = kb - 1;
+            leaf_inverse_diag(lt, w, dinv, a, lane);
+            for (int b = 0; b < a; ++b) {
+                const d4 tacc = leaf_inverse_t(lt, w, a, b, lane);
+                leaf_inverse_w(w, tacc, a, b, lane);
+            }
         }
         __syncthreads();
         if (wv > kb) {
@@ -422,15 +477,22 @@ __device__ __forceinline__ void leaf_factor_panels(const T* __restrict__ Mb, int
             }
         }
     }
+    // row 3 of the inverse: W_33 on wave 3, T_3b = sum_m L_3m W_mb on wave b (b = 0, 1, 2), then W_3b = -W_33 T_3b
+    d4 tacc = {0.0, 0.0, 0.0, 0.0};
+    if (wv == 3) leaf_inverse_diag(lt, w, dinv, 3, lane);
+    else tacc = leaf_inverse_t(lt, w, 3, wv, lane);
+    __syncthreads();
+    if (wv < 3) leaf_inverse_w(w, tacc, 3, wv, lane);
+    __syncthreads();
 }
 
 template <typename T>
 __device__ __forceinline__ void leaf_body(unsigned char* lds, int k, T* __restrict__ M, T* __restrict__ W, size_t mat,
                                           int npad, int jb, double* __restrict__ logdet, int* __restrict__ info) {
     double (*lt)[LEAF_LDT] = (double (*)[LEAF_LDT])lds;                   // lt[col][row] = L[row][col]
-    double* scratch = (double*)lds + TS * LEAF_LDT;
-    double (*w)[LEAF_LDT] = (double (*)[LEAF_LDT])scratch;                // the inverse; overlays the factor's scratch
-    double* dinv = scratch + LEAF_W_DOUBLES;
+    double (*w)[LEAF_LDT] = (double (*)[LEAF_LDT])((double*)lds + TS * LEAF_LDT);     // w[row][col] = (L^-1)[row][col]
+    double* scratch = (double*)lds + 2 * TS * LEAF_LDT;
+    double* dinv = scratch + LEAF_SCR;
     double* pivs = dinv + TS;
     int* bad = (int*)(pivs + TS);
     const int tid = threadIdx.x;
@@ -438,11 +500,14 @@ __device__ __forceinline__ void leaf_body(unsigned char* lds, int k, T* __restri
     T* Wb = W + (size_t)k * mat + (size_t)jb * TS * npad + (size_t)jb * TS;
     const int cj = tid & 63;
     const int rg = tid >> 6;
-    leaf_factor_panels<T>(Mb, npad, lt, scratch, dinv, pivs, bad, jb);
+    leaf_factor_invert<T>(Mb, npad, lt, w, scratch, dinv, pivs, bad, jb);
 #pragma unroll
     for (int m = 0; m < 16; ++m) {
         const int i = rg + 4 * m;
         Mb[(size_t)i * npad + cj] = (T)lt[cj][i];
+        Wb[(size_t)i * npad + cj] = (T)(cj <= i ? w[i][cj] : 0.0);
+        // the 128x128 tile kernels read whole diagonal 128-blocks of W: keep the quadrant above this block zero
+        if ((jb & 1) == 0) Wb[(size_t)i * npad + TS + cj] = (T)0;
     }
     if (tid < TS) {   // wave 0: 1/2 sum log(pivot)
         double lg = 0.5 * log(pivs[tid]);
@@ -453,61 +518,10 @@ __device__ __forceinline__ void leaf_body(unsigned char* lds, int k, T* __restri
             if (fb && info[k] == 0) info[k] = fb;
         }
     }
-    // ---- inverse of the 64x64 lower-triangular block, blocked by 16 ----
-    // (a) the four 16x16 diagonal blocks: thread = one column, kept in registers (solve L w = e_cl)
-    if (tid < TS) {
-        const int b0 = (tid >> 4) * 16;
-        const int cl = tid & 15;
-        double wc[16];
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            double sacc = i == cl ? -1.0 : 0.0;
-#pragma unroll
-            for (int m = 0; m < i; ++m) sacc = fma(lt[b0 + m][b0 + i], wc[m], sacc);
-            wc[i] = -sacc * dinv[b0 + i];
-        }
-#pragma unroll
-        for (int i = 0; i < 16; ++i) w[b0 + i][b0 + cl] = wc[i];
-    }
-    __syncthreads();
-    // (b) off-diagonal 16x16 blocks by distance:  T_ab = sum_{m=b}^{a-1} L_am W_mb ;  W_ab = -W_aa T_ab,
-    // one wave per block pair on the fp64 MFMA.  The accumulator of T (lane: col = l & 15, rows (l >> 4) + 4 reg)
-    // is exactly the B-operand fragment of the second product (k = 4 step + (l >> 4)), so it is fed straight back.
-    {
-        const int wave = tid >> 6, lane = tid & 63;
-        const int li = lane & 15, lq = lane >> 4;
-        for (int dist = 1; dist < 4; ++dist) {
-            if (wave + dist < 4) {
-                const int bb = wave, ab = wave + dist;
-                d4 tacc = {0.0, 0.0, 0.0, 0.0};
-                for (int mb = bb; mb < ab; ++mb) {
-#pragma unroll
-                    for (int st = 0; st < 4; ++st)
-                        tacc = __builtin_amdgcn_mfma_f64_16x16x4f64(lt[mb * 16 + 4 * st + lq][ab * 16 + li],
-                                                                    w[mb * 16 + 4 * st + lq][bb * 16 + li], tacc, 0, 0, 0);
-                }
-                d4 wacc = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-                for (int st = 0; st < 4; ++st)
-                    wacc = __builtin_amdgcn_mfma_f64_16x16x4f64(w[ab * 16 + li][ab * 16 + 4 * st + lq], tacc[st], wacc,
-                                                                0, 0, 0);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) w[ab * 16 + lq + 4 * e][bb * 16 + li] = -wacc[e];
-            }
-            __syncthreads();
-        }
-    }
-#pragma unroll
-    for (int m = 0; m < 16; ++m) {
-        const int i = rg + 4 * m;
-        Wb[(size_t)i * npad + cj] = (T)(cj <= i ? w[i][cj] : 0.0);
-        // the 128x128 tile kernels read whole diagonal 128-blocks of W: keep the quadrant above this block zero
-        if ((jb & 1) == 0) Wb[(size_t)i * npad + TS + cj] = (T)0;
-    }
 }
 
 template <typename T>
-__global__ __launch_bounds__(256) void leaf_kernel(T* __restrict__ M, T* __restrict__ W, size_t mat, int npad, int jb,
+__global__ __launch_bounds__(256, 2) void leaf_kernel(T* __restrict__ M, T* __restrict__ W, size_t mat, int npad, int jb,
                                                    double* __restrict__ logdet, int* __restrict__ info) {
     __shared__ __align__(16) unsigned char lds[LEAF_LDS_BYTES];
     leaf_body<T>(lds, blockIdx.x, M, W, mat, npad, jb, logdet, info);
@@ -889,7 +903,7 @@ __global__ __launch_bounds__(256, 2) void syrk_rect_kernel(GemmArgs g) {
 // which touch columns the chain of the current panel neither reads nor writes.  No inter-workgroup dependency
 // exists inside such a launch; stream order between launches provides all the ordering.
 template <typename T>
-__global__ __launch_bounds__(256) void leaf_fill_kernel(T* __restrict__ M, T* __restrict__ W, size_t mat, int npad, int jb,
+__global__ __launch_bounds__(256, 2) void leaf_fill_kernel(T* __restrict__ M, T* __restrict__ W, size_t mat, int npad, int jb,
                                                         double* __restrict__ logdet, int* __restrict__ info,
                                                         int q, GemmArgs f) {
     __shared__ __align__(16) unsigned char lds[LEAF_LDS_BYTES];
@@ -898,7 +912,7 @@ __global__ __launch_bounds__(256) void leaf_fill_kernel(T* __restrict__ M, T* __
 }
 
 // ---------------------------------------------------------------------------------------------------
-// One launch per 64-column step of the panel chain (lcgp_set_tuning key 12, default on).
+// One launch per 64-column step of the panel chain.
 // The three dependent launches of a step (diagonal block -> panel TRMM -> rank-64 update of the rest of the panel)
 // are re-cut so that a step needs ONE launch X_c with no dependency between its workgroups:
 //   * TRMM tiles (r, c), r > c:   L[r,c] = (A[r,c] - L[r,c-1] L[c,c-1]^T) W_cc^T   -- the contribution of the
@@ -998,7 +1012,7 @@ struct Tile64 {          // 64x64 tile on 256 threads: wave (wm, wn) owns a 32x3
 };
 
 template <typename T>
-__global__ __launch_bounds__(256) void chain_step_kernel(StepArgs a) {
+__global__ __launch_bounds__(256, 2) void chain_step_kernel(StepArgs a) {
     __shared__ __align__(16) unsigned char lds[LEAF_LDS_BYTES];
     typedef Tile64<T> TL;
     int b = blockIdx.x;

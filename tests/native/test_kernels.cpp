@@ -292,9 +292,10 @@ static void run_case(int n, int d, int p, int q, bool rep, unsigned seed) {
         for (size_t i = 0; i < x0.size(); ++i) x0[i] = (double)x0s[i];
         void *dx0, *dscr;
         double *dgh, *dgv;
-        int n0pad = (n0 + 63) / 64 * 64, npad = (n + 127) / 128 * 128;
+        size_t scr_bytes = 0;
+        LCHK(lcgp_predict_scratch_bytes(dtype, n, q, n0, &scr_bytes));
         HIPCHK(hipMalloc(&dx0, x0s.size() * sizeof(T)));
-        HIPCHK(hipMalloc(&dscr, (size_t)2 * n0pad * npad * sizeof(T)));
+        HIPCHK(hipMalloc(&dscr, scr_bytes));
         HIPCHK(hipMalloc(&dgh, (size_t)q * n0 * 8));
         HIPCHK(hipMalloc(&dgv, (size_t)q * n0 * 8));
         HIPCHK(hipMemcpy(dx0, x0s.data(), x0s.size() * sizeof(T), hipMemcpyHostToDevice));

@@ -18,6 +18,18 @@ def test_native_library_is_the_one_running():
     assert _hip.load().lcgp_version() >= 200
 
 
+def test_c_abi_from_plain_cpp_without_torch():
+    """tests/native/test_kernels (built by `make` / __graft_entry__.build()) links liblcgp_hip.so from plain C++ -- no
+    Python, no torch -- and checks every entry point against host formulas: the C ABI is usable on its own."""
+    import os
+    import subprocess
+    drv = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'native', 'test_kernels')
+    if not os.path.exists(drv):
+        pytest.skip('native driver not built')
+    res = subprocess.run([drv, '64', '200', '700'], capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0 and 'ALL OK' in res.stdout, res.stdout[-2000:] + res.stderr[-1000:]
+
+
 def _rep_data(seed=0, n_unique=20, p=4, d=2, reps=3):
     rng = np.random.default_rng(seed)
     xu = rng.uniform(0, 1, (n_unique, d))
