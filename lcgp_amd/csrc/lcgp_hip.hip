@@ -1270,31 +1270,32 @@ __global__ __launch_bounds__(256) void finalize_kernel(int n, int npad, int d, i
                                                        const double* __restrict__ logdet, const int* __restrict__ info,
                                                        const double* __restrict__ theta, double* __restrict__ out) {
     __shared__ double sh[4];
+    __shared__ double grp[256];
+    __shared__ double sums[DMAX + 2];
     const int k = blockIdx.x;
     const int tid = threadIdx.x;
     const double* th = th_row(theta, d, p, k);
     double* o = out + (size_t)k * (d + 5 + p);
     const T* bk = b + (size_t)k * npad;
     const T* zk = z + (size_t)k * npad;
-    // tile partials
-    // every load first (one pass over the tile partials, all d + 2 sums at once), then the block reductions
-    double sums[DMAX + 2];
-#pragma unroll
-    for (int e = 0; e < DMAX + 2; ++e) sums[e] = 0.0;
-#pragma unroll 4
-    for (int t = tid; t < ntile; t += 256) {
-        const double* pt = part + ((size_t)k * ntile + t) * (DMAX + 2);
-#pragma unroll
-        for (int e = 0; e < DMAX + 2; ++e)
-            if (e < d + 2) sums[e] += pt[e];
-    }
+    // tile partials: thread = (entry e = tid % ne, group g = tid / ne) sums its entry over the tiles g, g + ng, ...;
+    // entry e then adds its ng group sums in a fixed order (one pass over the partials, deterministic)
+    const int ne = d + 2, ng = 256 / ne;
+    const int e = tid % ne, g = tid / ne;
+    double acc = 0.0;
+    if (g < ng)
+        for (int t = g; t < ntile; t += ng) acc += part[((size_t)k * ntile + t) * (DMAX + 2) + e];
+    grp[tid] = acc;
     double v = 0.0;
 #pragma unroll 4
     for (int i = tid; i < n; i += 256) v += (double)bk[i] * ((double)bk[i] - (double)zk[i]);
-#pragma unroll
-    for (int e = 0; e < DMAX + 2; ++e)
-        if (e < d + 2) sums[e] = block_sum(sums[e], sh, tid);
-    const double quad = block_sum(v, sh, tid);
+    __syncthreads();
+    if (tid < ne) {
+        double s = 0.0;
+        for (int gg = 0; gg < ng; ++gg) s += grp[gg * ne + tid];
+        sums[tid] = s;
+    }
+    const double quad = block_sum(v, sh, tid);          // (its barriers also publish sums[])
     const double scale = th[d], nug = th[d + 1];
     const double nt = nug / (1.0 + nug);
     if (tid == 0) {
