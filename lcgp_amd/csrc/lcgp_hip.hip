@@ -1283,8 +1283,20 @@ __global__ __launch_bounds__(256) void finalize_kernel(int n, int npad, int d, i
     const int ne = d + 2, ng = 256 / ne;
     const int e = tid % ne, g = tid / ne;
     double acc = 0.0;
-    if (g < ng)
-        for (int t = g; t < ntile; t += ng) acc += part[((size_t)k * ntile + t) * (DMAX + 2) + e];
+    if (g < ng) {
+        // four independent chains (the loads of one chain would otherwise wait for each other), combined in a fixed order
+        double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+        const double* pk = part + (size_t)k * ntile * (DMAX + 2) + e;
+        int t = g;
+        for (; t + 3 * ng < ntile; t += 4 * ng) {
+            a0 += pk[(size_t)t * (DMAX + 2)];
+            a1 += pk[(size_t)(t + ng) * (DMAX + 2)];
+            a2 += pk[(size_t)(t + 2 * ng) * (DMAX + 2)];
+            a3 += pk[(size_t)(t + 3 * ng) * (DMAX + 2)];
+        }
+        for (; t < ntile; t += ng) a0 += pk[(size_t)t * (DMAX + 2)];
+        acc = (a0 + a1) + (a2 + a3);
+    }
     grp[tid] = acc;
     double v = 0.0;
 #pragma unroll 4
