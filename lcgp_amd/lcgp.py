@@ -463,23 +463,25 @@ class LCGP:
         """scipy L-BFGS-B with default options on the unconstrained vector (lcgp.py:537-540).
 
         A trial point at which some I + D_k C_k is not numerically positive definite (possible in float32 or at the
-        SoftClip edges) does not abort the fit: the reference's eigendecomposition form returns a non-finite or huge
-        value there and the line search backs off, so the closure reports a huge finite value with a zero gradient.
-        `loss()` / `neglpost()` called directly still raise.  (info is all-reduced, so every rank takes the same branch.)"""
+        SoftClip edges) does not abort the fit: the reference's eigendecomposition form returns a non-finite value there,
+        which leaves the line search nothing to interpolate with.  Here the closure reports a value clearly ABOVE the
+        last successful one (f_last + 1 + |f_last|, zero gradient): the line search's interpolation then shortens the
+        step and tries again (a far larger penalty would shrink the step to nothing and end the run with a spurious
+        "converged").  `loss()` / `neglpost()` called directly still raise, and so does a failure at the very first
+        evaluation (nothing to back off to).  (info is all-reduced, so every rank takes the same branch.)"""
         if self.submethod not in self.submethod_loss_map:
             raise ValueError("Invalid submethod. Choices are 'full' or 'rep'.")
         u0 = self._get_flat()
-        first = []
+        last = []
 
         def fun(u):
             try:
                 val, g = self.loss_and_grad(u)
             except np.linalg.LinAlgError:
-                if not first:
+                if not last:
                     raise
-                return 1e10 + 1e6 * abs(first[0]), np.zeros_like(u)
-            if not first:
-                first.append(val)
+                return last[0] + 1.0 + abs(last[0]), np.zeros_like(u)
+            last[:] = [val]
             return val, g
 
         res = sopt.minimize(fun, u0, jac=True, method='L-BFGS-B')

@@ -357,3 +357,40 @@ def test_drop_in_import_shim_and_metrics():
     assert abs(evaluation.dss(y, m, v, use_diag=True) - orc.dss_diag(y, m, v)) < 1e-12
     cov = np.stack([np.diag(v[:, i]) for i in range(50)], axis=2)
     assert abs(evaluation.dss(y, m, cov, use_diag=False) - evaluation.dss(y, m, v, use_diag=True)) < 1e-10
+
+
+def test_fit_backs_off_from_a_non_positive_definite_trial_point():
+    """A trial point at which some I + D_k C_k is not numerically positive definite (float32, SoftClip edges) must not
+    abort fit(): the closure reports a huge finite value with a zero gradient and L-BFGS-B's line search backs off (the
+    reference's eigendecomposition form yields a non-finite / huge value there).  loss() called directly still raises."""
+    x, y = synth.make_full(41, 40, 2, 3, 2)
+    m = patch_engine(LCGP(y=y, x=x, q=2))
+    eng = m._get_engine()
+    real = eng.evaluate_partial
+    calls = {'n': 0, 'bad': 0}
+
+    def flaky(theta_rows):
+        calls['n'] += 1
+        part = real(theta_rows)
+        if calls['n'] in (3, 4):                 # two consecutive trial points "fail" (info = 7 on component 0)
+            calls['bad'] += 1
+            part = part.clone()
+            part[1] = 7.0
+        return part
+    eng.evaluate_partial = flaky
+    before = None
+    eng.evaluate_partial = real
+    before = float(m.loss())
+    eng.evaluate_partial = flaky
+    calls['n'] = 0
+    m.fit()
+    assert calls['bad'] == 2 and m.opt_result.nfev > 5
+    eng.evaluate_partial = real
+    assert float(m.loss()) < before
+    # outside fit() the failure is an exception
+    eng.evaluate_partial = lambda th: (lambda p: (p.__setitem__(1, 3.0), p)[1])(real(th).clone())
+    with pytest.raises(np.linalg.LinAlgError):
+        m.loss()
+    # ... and a failure at the very first evaluation of fit() has no value to back off to: it raises as well
+    with pytest.raises(np.linalg.LinAlgError):
+        m.fit()
