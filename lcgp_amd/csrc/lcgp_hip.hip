@@ -6,10 +6,11 @@
 // 64x64 diagonal blocks in LDS, fp64 MFMA trailing updates)  ->  W = L^-1 (level-parallel TRMMs)
 // ->  A^-1 = W^T W (one MFMA launch)  ->  z = A^-1 b  ->  fused contraction of
 // G = s s^T o (D/2 A^-1 - z z^T/2) with dC/dtheta recomputed on the fly from x.
-// All components of the rank are batched in every launch (blockIdx.y = component).
+// All components of the rank are batched in every launch.  The library keeps no state: the launch schedule is a
+// per-call argument (lcgp_sched), nothing is allocated, no stream or event is created.
 //
-// Layout in HBM: per component three npad x npad row-major matrices (npad = n rounded up to 64,
-// the padding is the identity so every kernel works on whole 64x64 tiles):
+// Layout in HBM: per component three npad x npad row-major matrices (npad = n rounded up to 128,
+// the padding is the identity so every kernel works on whole 64x64 / 128x128 tiles):
 //   M : A, then L (lower tiles)      W : L^-1 (lower tiles)      V : scratch, then A^-1 (lower tiles)
 #include <hip/hip_runtime.h>
 #include <stdint.h>
