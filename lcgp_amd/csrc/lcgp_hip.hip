@@ -336,20 +336,66 @@ __device__ __forceinline__ double fast_rcp(double a) {
 // ---- in-wave panel factorisation of the diagonal block ----
 // The 64x64 block is split into four 16-column panels, one per wave.  Wave w keeps block column w as fp64 MFMA
 // accumulators (lane (c = l & 15, g = l >> 4), reg e <-> row 16 rb + g + 4 e, column 16 w + c).  When its turn
-// comes it turns the panel into ROW layout through a private LDS scratch (lane = row, 16 registers = the panel's
-// columns) and factors it without leaving the wave: per pivot the pivot row is broadcast with v_readlane (SGPRs),
-// the update a_lc -= (u_l / d) u_pc is one FMA per remaining column and needs no barrier and no LDS; columns stay
-// un-scaled (u = l sqrt(d)) on the chain, the 1/sqrt(d) scaling runs beside it.  The finished panel goes to LDS as
-// lt[col][row]; after ONE barrier the waves to its right apply it to their accumulators with 16x16x4 MFMAs.
-// Chain per block: 64 x (readlane, rcp + 2 Newton steps, 2 FMAs) + 3 barriers instead of 32 barriers with an LDS
-// round trip each.
-__device__ __forceinline__ double readlane_f64(double v, int lane) {
-    union { double d; int i[2]; } u;
-    u.d = v;
-    u.i[0] = __builtin_amdgcn_readlane(u.i[0], lane);
-    u.i[1] = __builtin_amdgcn_readlane(u.i[1], lane);
-    return u.d;
+// comes it re-reads the panel through a private LDS scratch into a layout made for the 16-pivot chain:
+//   lane (i = l & 15, j = l >> 4):  rD[c] = row i of the panel's 16x16 DIAGONAL block (the same in all four lane rows),
+//                                   rL[c] = row i of the j-th 16x16 block BELOW it (j < 3 - kb)
+// so that everything a pivot step broadcasts lives in its own 16-lane row: the update
+//   a_ic -= (u_i / d) u_c        u = the un-scaled pivot column (u = l sqrt(d)), u_c held by lane c of the row
+// is ONE v_fmac_f64 with the DPP modifier row_newbcast:c on u (fp64 DPP exists for exactly this control) -- no
+// v_readlane pair, no SGPR hazard nop, no LDS, no barrier.  The 1/sqrt(d) scaling runs after the chain.  The finished
+// panel goes to LDS as lt[col][row]; after ONE barrier the waves to its right apply it with 16x16x4 MFMAs.
+// Chain per panel: 16 x (broadcast, rcp + 2 Newton steps, 2 products) with the 2 (15 - s) updates filling the shadow.
+template <int C>
+__device__ __forceinline__ double row_bcast(double x) {        // lane C of every 16-lane row -> the whole row
+    double o;
+    // s_nop 1: a DPP read needs two wait states after a VALU write of its source (x has usually just been produced)
+    asm("s_nop 1\n\tv_mov_b64_dpp %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "=v"(o) : "v"(x), "n"(C));
+    return o;
 }
+
+template <int C>
+__device__ __forceinline__ void fmac_row_bcast(double& acc, double u, double v) {   // acc += u[lane C of the row] * v
+    asm("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(u), "v"(v), "n"(C));
+}
+
+template <int S, int C>
+struct PivotCols {      // columns C .. 15 of pivot step S
+    static __device__ __forceinline__ void run(double (&rD)[16], double (&rL)[16], double vD, double vL) {
+        if constexpr (C < 16) {
+            fmac_row_bcast<C>(rD[C], rD[S], vD);
+            fmac_row_bcast<C>(rL[C], rD[S], vL);
+            PivotCols<S, C + 1>::run(rD, rL, vD, vL);
+        }
+    }
+};
+
+template <int S>
+struct PivotSteps {     // pivot steps S .. 15; dmine collects the pivot of row i (lane i of each row)
+    static __device__ __forceinline__ void run(double (&rD)[16], double (&rL)[16], double& dmine, int i) {
+        if constexpr (S < 16) {
+            // rD[S] was last written by the previous step's first update: the broadcast carries the DPP wait states,
+            // and every fmac of this step depends on it through vD / vL
+            const double dp = row_bcast<S>(rD[S]);
+            dmine = i == S ? rD[S] : dmine;
+            const double rdp = fast_rcp(dp);
+            const double vD = -rD[S] * rdp, vL = -rL[S] * rdp;
+            PivotCols<S, S + 1>::run(rD, rL, vD, vL);
+            PivotSteps<S + 1>::run(rD, rL, dmine, i);
+        }
+    }
+};
+
+template <int S>
+struct ScaleCols {      // l = u / sqrt(pivot): column S times the reciprocal root held by lane S of the row
+    static __device__ __forceinline__ void run(double (&rD)[16], double (&rL)[16], double rsl) {
+        if constexpr (S < 16) {
+            const double f = row_bcast<S>(rsl);
+            rD[S] *= f;
+            rL[S] *= f;
+            ScaleCols<S + 1>::run(rD, rL, rsl);
+        }
+    }
+};
 
 __device__ __forceinline__ double fast_rsqrt(double a) {
     double y = __builtin_amdgcn_rsq(a);
@@ -433,28 +479,32 @@ __device__ __forceinline__ void leaf_factor_invert(const T* __restrict__ Mb, int
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
                     if (rb >= kb) S[rb * 16 + lq + 4 * e][li] = acc[rb][e];
-            double r[16];
-#pragma unroll
-            for (int c = 0; c < 16; ++c) r[c] = S[lane][c];
+            const int nlow = 3 - kb;                  // 16-row blocks below the diagonal block of this panel
             const int base = kb * 16;
-            double dmine = 1.0;                       // the pivot of row `lane` (lanes base .. base + 15)
+            double rD[16], rL[16];
+            const int lrow = lq < nlow ? base + 16 * (1 + lq) + li : base + li;      // (unconditional read, then select)
 #pragma unroll
-            for (int s = 0; s < 16; ++s) {
-                const double u = r[s];
-                const double dp = readlane_f64(u, base + s);
-                dmine = lane == base + s ? u : dmine;
-                const double v = -u * fast_rcp(dp);
-#pragma unroll
-                for (int c = s + 1; c < 16; ++c) r[c] = fma(v, readlane_f64(u, base + c), r[c]);
+            for (int c = 0; c < 16; ++c) {
+                rD[c] = S[base + li][c];
+                const double below = S[lrow][c];
+                rL[c] = lq < nlow ? below : 0.0;
             }
-            const double rsl = fast_rsqrt(dmine);     // off the chain: l = u / sqrt(pivot)
-#pragma unroll
-            for (int s = 0; s < 16; ++s) r[s] *= readlane_f64(rsl, base + s);
-            if (lane >= base && lane < base + 16) { dinv[lane] = rsl; pivs[lane] = dmine; }
-            const unsigned long long bm = (__ballot(!(dmine > 0.0)) >> base) & 0xffffull;
+            double dmine = 1.0;                       // the pivot of row li of the diagonal block
+            PivotSteps<0>::run(rD, rL, dmine, li);
+            const double rsl = fast_rsqrt(dmine);     // off the chain
+            ScaleCols<0>::run(rD, rL, rsl);
+            if (lq == 0) { dinv[base + li] = rsl; pivs[base + li] = dmine; }
+            const unsigned long long bm = __ballot(!(dmine > 0.0)) & 0xffffull;
             if (bm) first_bad = jb * TS + base + __ffsll((long long)bm);
+            // lt[col][row]: lane rows 0 .. nlow-1 hold the blocks below the diagonal one, the other kb lane rows write the
+            // zeros of the kb blocks above it; lane row 0 also writes the diagonal block (zero above the diagonal)
+            const int row = lq < nlow ? base + 16 * (1 + lq) + li : 16 * (lq - nlow) + li;
 #pragma unroll
-            for (int m = 0; m < 16; ++m) lt[kb * 16 + m][lane] = lane >= kb * 16 + m ? r[m] : 0.0;
+            for (int m = 0; m < 16; ++m) lt[base + m][row] = lq < nlow ? rL[m] : 0.0;
+            if (lq == 0) {
+#pragma unroll
+                for (int m = 0; m < 16; ++m) lt[base + m][base + li] = li >= m ? rD[m] : 0.0;
+            }
             if (lane == 0) bad[kb] = first_bad;
         } else if (wv == kb - 1) {
             // row kb-1 of the inverse (panel kb-1 and everything it needs became visible at the last barrier)
@@ -552,6 +602,17 @@ struct GemmArgs {
 
 // one K-stage (KT = 16 k values) of a TM-row operand tile: global -> registers -> LDS [k][m], ld = TM + 16;
 // NT threads move TM * KT elements, EPT = TM * KT / NT consecutive ones each
+// LDS image of a stage: [k][m] with row length LD = TM + 16 (= 16 mod 32 doubles: the two k rows a 32-lane ds_read_b64
+// group touches lie in disjoint bank halves) and the column index XOR-ed with (k & 12).  The XOR is what makes the
+// TRANSPOSING store of a k-contiguous operand (MK: a lane holds 4 consecutive k of one row m) conflict-free: a
+// ds_write_b64 is served in groups of 16 contiguous lanes over 32 banks (MI355X_MICROARCH.md, LDS), and those 16 lanes
+// are 4 rows m x 4 k-quads -- without the XOR all four quads of a row hit one bank pair (4-way conflict on every
+// store of every stage; same-box A/B: 11.20 -> 10.95 ms per evaluation).  Within one k row the XOR only permutes each
+// aligned group of 16 columns, so the fragment reads (16 consecutive columns of one row) stay conflict-free, and for
+// the m-contiguous operand layout (KM: 4 consecutive m per lane) it moves whole aligned quads, so the 16-byte stores stay.
+__device__ __forceinline__ constexpr int lds_swz(int k) { return k & 12; }
+static_assert(KT == 16, "lds_swz assumes 16 k rows per stage");
+
 template <typename T, int L, int TM, int NT>
 __device__ __forceinline__ void load_stage(const T* __restrict__ P, int ld, int ks, T (&reg)[TM * KT / NT], int tid) {
     constexpr int EPT = TM * KT / NT;
@@ -578,12 +639,12 @@ __device__ __forceinline__ void store_stage(T* __restrict__ S, const T (&reg)[TM
         constexpr int TPR = KT / EPT;
         const int m = tid / TPR, kk = (tid % TPR) * EPT;
 #pragma unroll
-        for (int e = 0; e < EPT; ++e) S[(kk + e) * LD + m] = reg[e];
+        for (int e = 0; e < EPT; ++e) S[(kk + e) * LD + (m ^ lds_swz(kk + e))] = reg[e];
     } else {
         constexpr int TPK = TM / EPT;
         const int kq = tid / TPK, mm = (tid % TPK) * EPT;
 #pragma unroll
-        for (int e = 0; e < EPT; ++e) S[kq * LD + mm + e] = reg[e];
+        for (int e = 0; e < EPT; ++e) S[kq * LD + (mm ^ lds_swz(kq)) + e] = reg[e];
     }
 }
 
@@ -718,11 +779,11 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, const int lin /*blo
             T af[MIM], bf[MIN];
 #pragma unroll
             for (int i = 0; i < MIM; ++i) {
-                const T v = as[krow + wm0 + i * 16 + (lane & 15)];
+                const T v = as[krow + wm0 + i * 16 + ((lane & 15) ^ lds_swz(4 * kk))];
                 af[i] = PRELOAD_C ? -v : v;
             }
 #pragma unroll
-            for (int j = 0; j < MIN; ++j) bf[j] = bs[krow + wn0 + j * 16 + (lane & 15)];
+            for (int j = 0; j < MIN; ++j) bf[j] = bs[krow + wn0 + j * 16 + ((lane & 15) ^ lds_swz(4 * kk))];
 #pragma unroll
             for (int i = 0; i < MIM; ++i)
 #pragma unroll
@@ -871,9 +932,9 @@ __device__ __forceinline__ void syrk_rect_body(const GemmArgs& g, const int lin,
                     const int kr = kk * 4 + (lane >> 4);
                     T af[4], bf[2];
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) af[i] = -as[kr * LDA + wm0 + i * 16 + (lane & 15)];
+                    for (int i = 0; i < 4; ++i) af[i] = -as[kr * LDA + wm0 + i * 16 + ((lane & 15) ^ lds_swz(4 * kk))];
 #pragma unroll
-                    for (int j = 0; j < 2; ++j) bf[j] = bs[kr * LDB + wn0 + j * 16 + (lane & 15)];
+                    for (int j = 0; j < 2; ++j) bf[j] = bs[kr * LDB + wn0 + j * 16 + ((lane & 15) ^ lds_swz(4 * kk))];
 #pragma unroll
                     for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -998,11 +1059,11 @@ struct Tile64 {          // 64x64 tile on 256 threads: wave (wm, wn) owns a 32x3
                 T af[2], bf[2];
 #pragma unroll
                 for (int i = 0; i < 2; ++i) {
-                    const T v = as[krow + wm0 + i * 16 + (lane & 15)];
+                    const T v = as[krow + wm0 + i * 16 + ((lane & 15) ^ lds_swz(4 * kk))];
                     af[i] = NEG ? -v : v;
                 }
 #pragma unroll
-                for (int j = 0; j < 2; ++j) bf[j] = bs[krow + wn0 + j * 16 + (lane & 15)];
+                for (int j = 0; j < 2; ++j) bf[j] = bs[krow + wn0 + j * 16 + ((lane & 15) ^ lds_swz(4 * kk))];
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
