@@ -457,7 +457,7 @@ __device__ __forceinline__ void leaf_inverse_w(double (*w)[LEAF_LDT], const d4& 
 // Factor AND inverse of the diagonal block.  While wave kb factors its 16-column panel (the 16-pivot chain, alone on its
 // SIMD), wave kb-1 -- idle otherwise -- forms row kb-1 of the inverse from the panels that are already final; only row 3
 // is left when the last panel is done, and that one is spread over all four waves.
-template <typename T>
+template <typename T, bool FROM_LDS>
 __device__ __forceinline__ void leaf_factor_invert(const T* __restrict__ Mb, int npad, double (*lt)[LEAF_LDT],
                                                    double (*w)[LEAF_LDT], double* scratch, double* dinv, double* pivs,
                                                    int* bad, int jb) {
@@ -468,7 +468,9 @@ __device__ __forceinline__ void leaf_factor_invert(const T* __restrict__ Mb, int
     for (int rb = 0; rb < 4; ++rb)
 #pragma unroll
         for (int e = 0; e < 4; ++e)
-            acc[rb][e] = rb >= wv ? (double)Mb[(size_t)(rb * 16 + lq + 4 * e) * npad + wv * 16 + li] : 0.0;
+            // FROM_LDS: the caller left the block in the w area (w itself is first written after the first barrier below)
+            acc[rb][e] = rb < wv ? 0.0 : FROM_LDS ? w[rb * 16 + lq + 4 * e][wv * 16 + li]
+                                                  : (double)Mb[(size_t)(rb * 16 + lq + 4 * e) * npad + wv * 16 + li];
     double (*S)[17] = (double (*)[17])scratch;
     int first_bad = 0;
 #pragma unroll 1
@@ -537,7 +539,7 @@ __device__ __forceinline__ void leaf_factor_invert(const T* __restrict__ Mb, int
     __syncthreads();
 }
 
-template <typename T>
+template <typename T, bool FROM_LDS = false>
 __device__ __forceinline__ void leaf_body(unsigned char* lds, int k, T* __restrict__ M, T* __restrict__ W, size_t mat,
                                           int npad, int jb, double* __restrict__ logdet, int* __restrict__ info) {
     double (*lt)[LEAF_LDT] = (double (*)[LEAF_LDT])lds;                   // lt[col][row] = L[row][col]
@@ -551,7 +553,7 @@ __device__ __forceinline__ void leaf_body(unsigned char* lds, int k, T* __restri
     T* Wb = W + (size_t)k * mat + (size_t)jb * TS * npad + (size_t)jb * TS;
     const int cj = tid & 63;
     const int rg = tid >> 6;
-    leaf_factor_invert<T>(Mb, npad, lt, w, scratch, dinv, pivs, bad, jb);
+    leaf_factor_invert<T, FROM_LDS>(Mb, npad, lt, w, scratch, dinv, pivs, bad, jb);
 #pragma unroll
     for (int m = 0; m < 16; ++m) {
         const int i = rg + 4 * m;
@@ -746,7 +748,7 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, const int lin /*blo
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wave = tid >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave-uniform: the sub-tile origin (wm0, wn0) stays in SGPRs
     const int wm0 = (wave >> 1) * WTM, wn0 = (wave & 1) * WTN;
     typedef typename Mfma<T>::acc_t acc_t;
     acc_t acc[MIM][MIN];
@@ -773,17 +775,18 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, const int lin /*blo
     auto compute_stage = [&](int buf) {
         const T* as = As + buf * KT * LD;
         const T* bs = Bs + buf * KT * LD;
+        const int l15 = lane & 15;
 #pragma unroll
         for (int kk = 0; kk < KT / 4; ++kk) {
             const int krow = (kk * 4 + (lane >> 4)) * LD;
             T af[MIM], bf[MIN];
 #pragma unroll
             for (int i = 0; i < MIM; ++i) {
-                const T v = as[krow + wm0 + i * 16 + ((lane & 15) ^ lds_swz(4 * kk))];
+                const T v = as[krow + wm0 + i * 16 + (l15 ^ lds_swz(4 * kk))];
                 af[i] = PRELOAD_C ? -v : v;
             }
 #pragma unroll
-            for (int j = 0; j < MIN; ++j) bf[j] = bs[krow + wn0 + j * 16 + ((lane & 15) ^ lds_swz(4 * kk))];
+            for (int j = 0; j < MIN; ++j) bf[j] = bs[krow + wn0 + j * 16 + (l15 ^ lds_swz(4 * kk))];
 #pragma unroll
             for (int i = 0; i < MIM; ++i)
 #pragma unroll
@@ -895,7 +898,7 @@ __device__ __forceinline__ void syrk_rect_body(const GemmArgs& g, const int lin,
     const T* A0 = (const T*)g.A + (size_t)k * g.sA + (size_t)R * TMR * g.ldA + (size_t)g.p0 * TS;
     const T* B0 = (const T*)g.B + (size_t)k * g.sB + (size_t)c * TNC * g.ldB + (size_t)g.p0 * TS;
     T* Ct = (T*)g.C + (size_t)k * g.sC + (size_t)R * TMR * g.ldC + (size_t)c * TNC;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm0 = (wave >> 1) * 64, wn0 = (wave & 1) * 32;
     typedef typename Mfma<T>::acc_t acc_t;
     acc_t acc[4][2];
@@ -1033,19 +1036,17 @@ struct Tile64 {          // 64x64 tile on 256 threads: wave (wm, wn) owns a 32x3
                 for (int e = 0; e < 4; ++e)
                     Ct[(size_t)(wm0 + i * 16 + Mfma<T>::row(lane, e)) * ld + wn0 + j * 16 + (lane & 15)] = acc[i][j][e];
     }
-    // acc += (NEG ? -1 : 1) * A B^T,  A and B 64x64 tiles (element (m, k) at P[m * ld + k]); all four K stages are
-    // fetched up front (one memory latency), then staged through the two LDS buffers
+    // One 64x64 operand (element (m, k) at P[m * ld + k]) into registers: all four K stages at once = one memory latency
+    static __device__ __forceinline__ void fetch(T (&p)[SPT][EPT], const T* P, int ld, int tid) {
+#pragma unroll
+        for (int s = 0; s < SPT; ++s) load_stage<T, MK, TS, NT>(P, ld, s * KT, p[s], tid);
+    }
+    // acc += (NEG ? -1 : 1) * A B^T from fetched operands, staged through the two LDS buffers of each
     template <bool NEG>
-    static __device__ __forceinline__ void mma(acc_t (&acc)[2][2], const T* A0, int ldA, const T* B0, int ldB, T* lds,
-                                               int tid, int lane, int wm0, int wn0) {
+    static __device__ __forceinline__ void mma_regs(acc_t (&acc)[2][2], const T (&pa)[SPT][EPT], const T (&pb)[SPT][EPT],
+                                                    T* lds, int tid, int lane, int wm0, int wn0) {
         T* As = lds;
         T* Bs = As + 2 * KT * LD;
-        T pa[SPT][EPT], pb[SPT][EPT];
-#pragma unroll
-        for (int s = 0; s < SPT; ++s) {
-            load_stage<T, MK, TS, NT>(A0, ldA, s * KT, pa[s], tid);
-            load_stage<T, MK, TS, NT>(B0, ldB, s * KT, pb[s], tid);
-        }
 #pragma unroll
         for (int s = 0; s < SPT; ++s) {
             store_stage<T, MK, TS, NT>(As + (s & 1) * KT * LD, pa[s], tid);
@@ -1071,6 +1072,78 @@ struct Tile64 {          // 64x64 tile on 256 threads: wave (wm, wn) owns a 32x3
             }
         }
     }
+    template <bool NEG>
+    static __device__ __forceinline__ void mma(acc_t (&acc)[2][2], const T* A0, int ldA, const T* B0, int ldB, T* lds,
+                                               int tid, int lane, int wm0, int wn0) {
+        T pa[SPT][EPT], pb[SPT][EPT];
+        fetch(pa, A0, ldA, tid);
+        fetch(pb, B0, ldB, tid);
+        mma_regs<NEG>(acc, pa, pb, lds, tid, lane, wm0, wn0);
+    }
+    // ---- products of the panel chain whose operand is a tile this workgroup has just computed: it stays on chip ----
+    // The accumulator tile as a complete k-major LDS operand, F[k * LD + (m ^ (k & 15))] = tile(m, k)   (TS * LD elements).
+    // The 16 contiguous lanes of a ds_write_b64 group hold 16 consecutive k of ONE row m here, i.e. 16 addresses LD
+    // apart = one bank pair (16-way conflict, 1.6 us per tile -- more than the L2 round trip it is meant to replace);
+    // XOR-ing the column with the low four bits of k gives the 16 lanes 16 different bank pairs, and a fragment read
+    // (16 consecutive columns of one k row) only sees a permutation of its aligned group.
+    static __device__ __forceinline__ void to_operand(const acc_t (&acc)[2][2], T* F, int lane, int wm0, int wn0) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    F[(wn0 + j * 16 + (lane & 15)) * LD + ((wm0 + i * 16 + Mfma<T>::row(lane, e)) ^ (lane & 15))] = acc[i][j][e];
+    }
+    // acc += (NEG ? -1 : 1) * A B^T,  A = F (to_operand), B fetched; Bs = two staging buffers of KT * LD elements.
+    // The first barrier inside also orders the writes of F.
+    template <bool NEG>
+    static __device__ __forceinline__ void mma_a_lds(acc_t (&acc)[2][2], const T* F, const T (&pb)[SPT][EPT], T* Bs, int tid,
+                                                     int lane, int wm0, int wn0) {
+#pragma unroll
+        for (int s = 0; s < SPT; ++s) {
+            store_stage<T, MK, TS, NT>(Bs + (s & 1) * KT * LD, pb[s], tid);
+            __syncthreads();
+            const T* as = F + s * KT * LD;
+            const T* bs = Bs + (s & 1) * KT * LD;
+#pragma unroll
+            for (int kk = 0; kk < KT / 4; ++kk) {
+                const int krow = (kk * 4 + (lane >> 4)) * LD;
+                T af[2], bf[2];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const T v = as[krow + wm0 + i * 16 + ((lane & 15) ^ (4 * kk + (lane >> 4)))];
+                    af[i] = NEG ? -v : v;
+                }
+#pragma unroll
+                for (int j = 0; j < 2; ++j) bf[j] = bs[krow + wn0 + j * 16 + ((lane & 15) ^ lds_swz(4 * kk))];
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) acc[i][j] = Mfma<T>::run(af[i], bf[j], acc[i][j]);
+            }
+        }
+    }
+    // acc += (NEG ? -1 : 1) * F^T-free form  X X^T  with X = the tile in F  (no staging, no barrier inside)
+    template <bool NEG>
+    static __device__ __forceinline__ void mma_ab_lds(acc_t (&acc)[2][2], const T* F, int lane, int wm0, int wn0) {
+#pragma unroll
+        for (int kk = 0; kk < TS / 4; ++kk) {
+            const int krow = (kk * 4 + (lane >> 4)) * LD;
+            T af[2], bf[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const T v = F[krow + wm0 + i * 16 + ((lane & 15) ^ ((4 * kk + (lane >> 4)) & 15))];
+                af[i] = NEG ? -v : v;
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j) bf[j] = F[krow + wn0 + j * 16 + ((lane & 15) ^ ((4 * kk + (lane >> 4)) & 15))];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = Mfma<T>::run(af[i], bf[j], acc[i][j]);
+        }
+    }
 };
 
 template <typename T>
@@ -1078,7 +1151,7 @@ __global__ __launch_bounds__(256, 2) void chain_step_kernel(StepArgs a) {
     __shared__ __align__(16) unsigned char lds[LEAF_LDS_BYTES];
     typedef Tile64<T> TL;
     int b = blockIdx.x;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm0 = (wave >> 1) * 32, wn0 = (wave & 1) * 32;
     const int ld = a.npad;
     // block order = longest first: the special tiles (chain of the step), the filler tiles, then the short ones
@@ -1097,26 +1170,49 @@ __global__ __launch_bounds__(256, 2) void chain_step_kernel(StepArgs a) {
         T* Mk = (T*)a.M + (size_t)k * a.mat;
         const T* Wk = (const T*)a.W + (size_t)k * a.mat;
         T* Ct = Mk + (size_t)r * TS * ld + (size_t)c * TS;
+        // The tile stays on chip between its products: after the previous column's contribution it goes to LDS as a
+        // complete k-major operand (F), L[r,c] = tile W_cc^T reads it from there, and so does the update of the row's
+        // diagonal block (X X^T with X = L[r,c]); only L[r,c] itself and the diagonal block travel to memory.  W_cc is
+        // fetched before the first product, so the second one starts without a memory latency of its own.
+        T* F = (T*)lds;                        // TS * LD elements (= the four staging buffers of TL::mma)
+        T* Bst = F + TS * TL::LD;              // two B staging buffers behind it
         typename TL::acc_t acc[2][2];
+        T pw[TL::SPT][TL::EPT];
+        TL::fetch(pw, Wk + (size_t)c * TS * ld + (size_t)c * TS, ld, tid);
+        TL::load(acc, Ct, ld, lane, wm0, wn0);
         if (c > a.J) {       // the previous column's contribution to this tile
-            TL::load(acc, Ct, ld, lane, wm0, wn0);
             TL::template mma<true>(acc, Mk + (size_t)r * TS * ld + (size_t)(c - 1) * TS, ld,
                                    Mk + (size_t)c * TS * ld + (size_t)(c - 1) * TS, ld, (T*)lds, tid, lane, wm0, wn0);
-            TL::store(acc, Ct, ld, lane, wm0, wn0);
-            __syncthreads();
+            __syncthreads();                   // the staging buffers become F
         }
+        TL::to_operand(acc, F, lane, wm0, wn0);
         TL::zero(acc);
-        TL::template mma<false>(acc, Ct, ld, Wk + (size_t)c * TS * ld + (size_t)c * TS, ld, (T*)lds, tid, lane, wm0, wn0);
-        TL::store(acc, Ct, ld, lane, wm0, wn0);         // L[r, c]  (every load of the old tile preceded the mma's barriers)
+        TL::template mma_a_lds<false>(acc, F, pw, Bst, tid, lane, wm0, wn0);
+        TL::store(acc, Ct, ld, lane, wm0, wn0);         // L[r, c]
         if (r < a.diag_end) {
-            __syncthreads();
             T* Dt = Mk + (size_t)r * TS * ld + (size_t)r * TS;
-            TL::load(acc, Dt, ld, lane, wm0, wn0);
-            TL::template mma<true>(acc, Ct, ld, Ct, ld, (T*)lds, tid, lane, wm0, wn0);
-            TL::store(acc, Dt, ld, lane, wm0, wn0);
+            typename TL::acc_t dacc[2][2];
+            TL::load(dacc, Dt, ld, lane, wm0, wn0);     // in flight across the barriers
+            __syncthreads();                            // every read of the old F has been issued and consumed
+            TL::to_operand(acc, F, lane, wm0, wn0);
+            __syncthreads();
+            TL::template mma_ab_lds<true>(dacc, F, lane, wm0, wn0);
             if (a.has_special && t == 0) {
+                // the updated diagonal block goes to the factorisation through LDS (leaf_body's w area, which that routine
+                // does not write before its first barrier); the block's L and inverse are what memory gets
                 __syncthreads();
-                leaf_body<T>(lds, k, (T*)a.M, (T*)a.W, a.mat, a.npad, c + 1, a.logdet, a.info);
+                double (*blk)[LEAF_LDT] = (double (*)[LEAF_LDT])((double*)lds + TS * LEAF_LDT);
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            blk[wm0 + i * 16 + Mfma<T>::row(lane, e)][wn0 + j * 16 + (lane & 15)] = (double)dacc[i][j][e];
+                __syncthreads();
+                leaf_body<T, true>(lds, k, (T*)a.M, (T*)a.W, a.mat, a.npad, c + 1, a.logdet, a.info);
+            } else {
+                TL::store(dacc, Dt, ld, lane, wm0, wn0);
             }
         }
         return;
@@ -1132,9 +1228,26 @@ __global__ __launch_bounds__(256, 2) void chain_step_kernel(StepArgs a) {
         T* Ct = Mk + (size_t)r * TS * ld + (size_t)cc * TS;
         typename TL::acc_t acc[2][2];
         TL::load(acc, Ct, ld, lane, wm0, wn0);
-        for (int j = a.J; j < a.c; ++j)
-            TL::template mma<true>(acc, Mk + (size_t)r * TS * ld + (size_t)j * TS, ld,
-                                   Mk + (size_t)cc * TS * ld + (size_t)j * TS, ld, (T*)lds, tid, lane, wm0, wn0);
+        // two operand sets: the next product's tiles are in flight while the current one runs
+        T pa[2][TL::SPT][TL::EPT], pb[2][TL::SPT][TL::EPT];
+        const T* Ar = Mk + (size_t)r * TS * ld;
+        const T* Br = Mk + (size_t)cc * TS * ld;
+        TL::fetch(pa[0], Ar + (size_t)a.J * TS, ld, tid);
+        TL::fetch(pb[0], Br + (size_t)a.J * TS, ld, tid);
+        for (int j = a.J; j < a.c; j += 2) {
+            if (j + 1 < a.c) {
+                TL::fetch(pa[1], Ar + (size_t)(j + 1) * TS, ld, tid);
+                TL::fetch(pb[1], Br + (size_t)(j + 1) * TS, ld, tid);
+            }
+            TL::template mma_regs<true>(acc, pa[0], pb[0], (T*)lds, tid, lane, wm0, wn0);
+            if (j + 1 < a.c) {
+                if (j + 2 < a.c) {
+                    TL::fetch(pa[0], Ar + (size_t)(j + 2) * TS, ld, tid);
+                    TL::fetch(pb[0], Br + (size_t)(j + 2) * TS, ld, tid);
+                }
+                TL::template mma_regs<true>(acc, pa[1], pb[1], (T*)lds, tid, lane, wm0, wn0);
+            }
+        }
         TL::store(acc, Ct, ld, lane, wm0, wn0);
     }
 }

@@ -34,27 +34,26 @@ PATCHES = [
      "        STAMP(8 + 3 * kb);\n    }\n    STAMP(18);\n    // row 3 of the inverse"),
     ("    if (wv < 3) leaf_inverse_w(w, tacc, 3, wv, lane);\n    __syncthreads();\n}",
      "    if (wv < 3) leaf_inverse_w(w, tacc, 3, wv, lane);\n    __syncthreads();\n    STAMP(19);\n}"),
-    ("    leaf_factor_invert<T>(Mb, npad, lt, w, scratch, dinv, pivs, bad, jb);",
-     "    STAMP(4);\n    leaf_factor_invert<T>(Mb, npad, lt, w, scratch, dinv, pivs, bad, jb);"),
+    ("    leaf_factor_invert<T, FROM_LDS>(Mb, npad, lt, w, scratch, dinv, pivs, bad, jb);",
+     "    STAMP(4);\n    leaf_factor_invert<T, FROM_LDS>(Mb, npad, lt, w, scratch, dinv, pivs, bad, jb);"),
     ("        if ((jb & 1) == 0) Wb[(size_t)i * npad + TS + cj] = (T)0;\n    }\n",
      "        if ((jb & 1) == 0) Wb[(size_t)i * npad + TS + cj] = (T)0;\n    }\n    STAMP(20);\n"),
     ("            if (fb && info[k] == 0) info[k] = fb;\n        }\n    }\n}",
      "            if (fb && info[k] == 0) info[k] = fb;\n        }\n    }\n    STAMP(21);\n}"),
-    ("        typename TL::acc_t acc[2][2];\n        if (c > a.J) {       // the previous column's contribution to this tile",
-     "        typename TL::acc_t acc[2][2];\n        STAMP(0);\n        if (c > a.J) {       // the previous column's contribution to this tile"),
-    ("            TL::store(acc, Ct, ld, lane, wm0, wn0);\n            __syncthreads();\n        }\n        TL::zero(acc);",
-     "            TL::store(acc, Ct, ld, lane, wm0, wn0);\n            __syncthreads();\n        }\n        STAMP(1);\n        TL::zero(acc);"),
-    ("        TL::store(acc, Ct, ld, lane, wm0, wn0);         // L[r, c]  (every load of the old tile preceded the mma's barriers)\n",
-     "        TL::store(acc, Ct, ld, lane, wm0, wn0);         // L[r, c]  (every load of the old tile preceded the mma's barriers)\n        STAMP(2);\n"),
-    ("            TL::store(acc, Dt, ld, lane, wm0, wn0);\n            if (a.has_special && t == 0) {",
-     "            TL::store(acc, Dt, ld, lane, wm0, wn0);\n            STAMP(3);\n            if (a.has_special && t == 0) {"),
+    ("        T pw[TL::SPT][TL::EPT];\n", "        T pw[TL::SPT][TL::EPT];\n        STAMP(0);\n"),
+    ("        TL::to_operand(acc, F, lane, wm0, wn0);\n        TL::zero(acc);",
+     "        STAMP(1);\n        TL::to_operand(acc, F, lane, wm0, wn0);\n        TL::zero(acc);"),
+    ("        TL::store(acc, Ct, ld, lane, wm0, wn0);         // L[r, c]\n",
+     "        TL::store(acc, Ct, ld, lane, wm0, wn0);         // L[r, c]\n        STAMP(2);\n"),
+    ("            TL::template mma_ab_lds<true>(dacc, F, lane, wm0, wn0);\n",
+     "            TL::template mma_ab_lds<true>(dacc, F, lane, wm0, wn0);\n            STAMP(3);\n"),
     ("const char* lcgp_source_hash(void) { return LCGP_SRC_HASH; }",
      "const char* lcgp_source_hash(void) { return LCGP_SRC_HASH; }\n"
      "int lcgp_debug_stamps(unsigned long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_st), sizeof(g_st)); }"),
 ]
 
-NAMES = {0: 'start', 1: 'previous column applied, tile stored', 2: 'L[c+1,c] = tile W_cc^T stored', 3: 'diagonal block updated, stored',
-         4: 'diagonal-block routine entered', 5: 'block in registers', 18: 'panels done', 19: 'row 3 of the inverse',
+NAMES = {0: 'start', 1: 'previous column applied', 2: 'L[c+1,c] = tile W_cc^T stored', 3: 'diagonal block updated',
+         4: 'diagonal-block routine entered', 5: 'block in registers (from LDS)', 18: 'panels done', 19: 'row 3 of the inverse',
          20: 'L and W stored', 21: 'log-determinant added'}
 for _kb in range(4):
     NAMES[6 + 3 * _kb] = 'panel %d factored (wave %d)' % (_kb, _kb)
