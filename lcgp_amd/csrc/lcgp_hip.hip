@@ -457,8 +457,30 @@ __device__ __forceinline__ void leaf_inverse_w(double (*w)[LEAF_LDT], const d4& 
 // Factor AND inverse of the diagonal block.  While wave kb factors its 16-column panel (the 16-pivot chain, alone on its
 // SIMD), wave kb-1 -- idle otherwise -- forms row kb-1 of the inverse from the panels that are already final; only row 3
 // is left when the last panel is done, and that one is spread over all four waves.
+// The results leave for memory as they become final, on waves that would otherwise wait at the panel's barrier: L panel
+// kb-1 and row block kb-2 of the inverse during panel kb (and the zero quadrant beside W during panel 0), so that only
+// the last panel, the last two row blocks and the log-determinant are left after the chain.
+template <typename T>
+__device__ __forceinline__ void leaf_store_l_panel(T* __restrict__ Mb, int npad, double (*lt)[LEAF_LDT], int pb, int lane) {
+    const int col = pb * 16 + (lane & 15);
+#pragma unroll
+    for (int m = 0; m < 16; ++m) {
+        const int i = (lane >> 4) + 4 * m;
+        Mb[(size_t)i * npad + col] = (T)lt[col][i];
+    }
+}
+
+template <typename T>
+__device__ __forceinline__ void leaf_store_w_rows(T* __restrict__ Wb, int npad, double (*w)[LEAF_LDT], int a, int lane) {
+#pragma unroll
+    for (int m = 0; m < 16; ++m) {
+        const int i = a * 16 + m;
+        Wb[(size_t)i * npad + lane] = (T)(lane <= i ? w[i][lane] : 0.0);
+    }
+}
+
 template <typename T, bool FROM_LDS>
-__device__ __forceinline__ void leaf_factor_invert(const T* __restrict__ Mb, int npad, double (*lt)[LEAF_LDT],
+__device__ __forceinline__ void leaf_factor_invert(T* __restrict__ Mb, T* __restrict__ Wb, int npad, double (*lt)[LEAF_LDT],
                                                    double (*w)[LEAF_LDT], double* scratch, double* dinv, double* pivs,
                                                    int* bad, int jb) {
     const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -516,6 +538,14 @@ __device__ __forceinline__ void leaf_factor_invert(const T* __restrict__ Mb, int
                 const d4 tacc = leaf_inverse_t(lt, w, a, b, lane);
                 leaf_inverse_w(w, tacc, a, b, lane);
             }
+        } else if (kb == 0) {
+            // the 128x128 tile kernels read whole diagonal 128-blocks of W: keep the quadrant above this block zero
+            if ((jb & 1) == 0)
+                for (int i = wv - 1; i < TS; i += 3) Wb[(size_t)i * npad + TS + lane] = (T)0;
+        } else if (wv == ((kb + 1) & 3)) {
+            leaf_store_l_panel<T>(Mb, npad, lt, kb - 1, lane);
+        } else if (kb >= 2 && wv == ((kb + 2) & 3)) {
+            leaf_store_w_rows<T>(Wb, npad, w, kb - 2, lane);
         }
         __syncthreads();
         if (wv > kb) {
@@ -536,7 +566,10 @@ __device__ __forceinline__ void leaf_factor_invert(const T* __restrict__ Mb, int
     else tacc = leaf_inverse_t(lt, w, 3, wv, lane);
     __syncthreads();
     if (wv < 3) leaf_inverse_w(w, tacc, 3, wv, lane);
+    else leaf_store_l_panel<T>(Mb, npad, lt, 3, lane);
     __syncthreads();
+    if (wv == 1) leaf_store_w_rows<T>(Wb, npad, w, 2, lane);
+    else if (wv == 2) leaf_store_w_rows<T>(Wb, npad, w, 3, lane);
 }
 
 template <typename T, bool FROM_LDS = false>
@@ -551,24 +584,18 @@ __device__ __forceinline__ void leaf_body(unsigned char* lds, int k, T* __restri
     const int tid = threadIdx.x;
     T* Mb = M + (size_t)k * mat + (size_t)jb * TS * npad + (size_t)jb * TS;
     T* Wb = W + (size_t)k * mat + (size_t)jb * TS * npad + (size_t)jb * TS;
-    const int cj = tid & 63;
-    const int rg = tid >> 6;
-    leaf_factor_invert<T, FROM_LDS>(Mb, npad, lt, w, scratch, dinv, pivs, bad, jb);
-#pragma unroll
-    for (int m = 0; m < 16; ++m) {
-        const int i = rg + 4 * m;
-        Mb[(size_t)i * npad + cj] = (T)lt[cj][i];
-        Wb[(size_t)i * npad + cj] = (T)(cj <= i ? w[i][cj] : 0.0);
-        // the 128x128 tile kernels read whole diagonal 128-blocks of W: keep the quadrant above this block zero
-        if ((jb & 1) == 0) Wb[(size_t)i * npad + TS + cj] = (T)0;
-    }
-    if (tid < TS) {   // wave 0: 1/2 sum log(pivot)
+    // the running log-determinant and status of the component are fetched now, so that the end is a store, not a round trip
+    double ld_prev = 0.0;
+    int info_prev = 0;
+    if (tid == 0) { ld_prev = logdet[k]; info_prev = info[k]; }
+    leaf_factor_invert<T, FROM_LDS>(Mb, Wb, npad, lt, w, scratch, dinv, pivs, bad, jb);
+    if (tid < TS) {   // wave 0 (the other waves are storing the last rows): 1/2 sum log(pivot)
         double lg = 0.5 * log(pivs[tid]);
         for (int off = 32; off > 0; off >>= 1) lg += __shfl_xor(lg, off);
         if (tid == 0) {
-            logdet[k] += lg;
+            logdet[k] = ld_prev + lg;
             const int fb = bad[0] ? bad[0] : bad[1] ? bad[1] : bad[2] ? bad[2] : bad[3];
-            if (fb && info[k] == 0) info[k] = fb;
+            if (fb && info_prev == 0) info[k] = fb;
         }
     }
 }

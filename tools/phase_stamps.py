@@ -32,14 +32,12 @@ PATCHES = [
      "    // row 3 of the inverse",
      "                                                                       0, 0, 0);\n            }\n        }\n"
      "        STAMP(8 + 3 * kb);\n    }\n    STAMP(18);\n    // row 3 of the inverse"),
-    ("    if (wv < 3) leaf_inverse_w(w, tacc, 3, wv, lane);\n    __syncthreads();\n}",
-     "    if (wv < 3) leaf_inverse_w(w, tacc, 3, wv, lane);\n    __syncthreads();\n    STAMP(19);\n}"),
-    ("    leaf_factor_invert<T, FROM_LDS>(Mb, npad, lt, w, scratch, dinv, pivs, bad, jb);",
-     "    STAMP(4);\n    leaf_factor_invert<T, FROM_LDS>(Mb, npad, lt, w, scratch, dinv, pivs, bad, jb);"),
-    ("        if ((jb & 1) == 0) Wb[(size_t)i * npad + TS + cj] = (T)0;\n    }\n",
-     "        if ((jb & 1) == 0) Wb[(size_t)i * npad + TS + cj] = (T)0;\n    }\n    STAMP(20);\n"),
-    ("            if (fb && info[k] == 0) info[k] = fb;\n        }\n    }\n}",
-     "            if (fb && info[k] == 0) info[k] = fb;\n        }\n    }\n    STAMP(21);\n}"),
+    ("    else leaf_store_l_panel<T>(Mb, npad, lt, 3, lane);\n    __syncthreads();\n",
+     "    else leaf_store_l_panel<T>(Mb, npad, lt, 3, lane);\n    __syncthreads();\n    STAMP(19);\n"),
+    ("    leaf_factor_invert<T, FROM_LDS>(Mb, Wb, npad, lt, w, scratch, dinv, pivs, bad, jb);",
+     "    STAMP(4);\n    leaf_factor_invert<T, FROM_LDS>(Mb, Wb, npad, lt, w, scratch, dinv, pivs, bad, jb);\n    STAMP(20);"),
+    ("            if (fb && info_prev == 0) info[k] = fb;\n        }\n    }\n}",
+     "            if (fb && info_prev == 0) info[k] = fb;\n        }\n    }\n    STAMP(21);\n}"),
     ("        T pw[TL::SPT][TL::EPT];\n", "        T pw[TL::SPT][TL::EPT];\n        STAMP(0);\n"),
     ("        TL::to_operand(acc, F, lane, wm0, wn0);\n        TL::zero(acc);",
      "        STAMP(1);\n        TL::to_operand(acc, F, lane, wm0, wn0);\n        TL::zero(acc);"),
@@ -54,7 +52,7 @@ PATCHES = [
 
 NAMES = {0: 'start', 1: 'previous column applied', 2: 'L[c+1,c] = tile W_cc^T stored', 3: 'diagonal block updated',
          4: 'diagonal-block routine entered', 5: 'block in registers (from LDS)', 18: 'panels done', 19: 'row 3 of the inverse',
-         20: 'L and W stored', 21: 'log-determinant added'}
+         20: 'last rows of L and W issued', 21: 'log-determinant stored'}
 for _kb in range(4):
     NAMES[6 + 3 * _kb] = 'panel %d factored (wave %d)' % (_kb, _kb)
     NAMES[7 + 3 * _kb] = 'panel %d barrier' % _kb
