@@ -627,6 +627,8 @@ struct GemmArgs {
     int t0;                                     // first tile of this launch (OP_SYRK: a launch may cover a sub-range)
     int skipq;                                  // OP_SYRK on 128-tiles: tile 0 leaves its top-left 64x64 quadrant alone
                                                 // (the diagonal block there is factored by the same launch, wide_leaf_kernel)
+    const void* bvec = nullptr;                 // OP_LAUUM on 128-tiles: b (npad per component) and the partial buffer of
+    double* part = nullptr;                     // z = A^-1 b, [component][tile][2][128]; null = no fused product
 };
 
 // one K-stage (KT = 16 k values) of a TM-row operand tile: global -> registers -> LDS [k][m], ld = TM + 16;
@@ -897,6 +899,60 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, const int lin /*blo
                     *dst = (T)v;
                 }
             }
+    if constexpr (OP == OP_LAUUM && TM == 128) {
+        // z = A^-1 b rides on the tiles of A^-1 while they are in registers (a pass over A^-1 of its own costs 0.1 ms at
+        // the headline size): tile (r, c) contributes p1 = V_rc b_c to z_r and, off the diagonal, p2 = V_rc^T b_r to z_c.
+        // Per lane the products over its own accumulators, then the 16 lanes of a row group (p1) / the four row groups
+        // (p2) by butterflies, then the two column halves / four row quarters of the waves through LDS; fixed orders.
+        if (g.part) {
+            __syncthreads();                                  // the stage buffers are free now
+            double* bsh = (double*)lds;                       // [0,128): b over the tile's rows, [128,256): over its columns
+            double* p1s = bsh + 256;                          // [2][128]
+            double* p2s = p1s + 256;                          // [4][128]
+            int r, c;
+            tri_decode(bid, r, c);
+            const T* bk = (const T*)g.bvec + (size_t)k * g.ldC;
+            if (tid < 256) bsh[tid] = (double)bk[(size_t)(tid < 128 ? r : c) * 128 + (tid & 127)];
+            __syncthreads();
+            const int l15 = lane & 15;
+            double s2[MIN];
+#pragma unroll
+            for (int j = 0; j < MIN; ++j) s2[j] = 0.0;
+#pragma unroll
+            for (int i = 0; i < MIM; ++i)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int row = wm0 + i * 16 + Mfma<T>::row(lane, e);
+                    const double br = bsh[row];
+                    double s1 = 0.0;
+#pragma unroll
+                    for (int j = 0; j < MIN; ++j) {
+                        const double v = (double)acc[i][j][e];
+                        s1 = fma(v, bsh[128 + wn0 + j * 16 + l15], s1);
+                        s2[j] = fma(v, br, s2[j]);
+                    }
+                    s1 += __shfl_xor(s1, 1);
+                    s1 += __shfl_xor(s1, 2);
+                    s1 += __shfl_xor(s1, 4);
+                    s1 += __shfl_xor(s1, 8);
+                    if (l15 == 0) p1s[(wave & 1) * 128 + row] = s1;
+                }
+#pragma unroll
+            for (int j = 0; j < MIN; ++j) {
+                double v = s2[j];
+                v += __shfl_xor(v, 16);
+                v += __shfl_xor(v, 32);
+                if ((lane >> 4) == 0) p2s[(wave >> 1) * 128 + wn0 + j * 16 + l15] = v;
+            }
+            __syncthreads();
+            double* pt = g.part + ((size_t)k * (g.nb * (g.nb + 1) / 2) + bid) * 256;
+            if (tid < 128) pt[tid] = p1s[tid] + p1s[128 + tid];
+            else if (tid < 256) {
+                const int cc = tid - 128;
+                pt[128 + cc] = (p2s[cc] + p2s[128 + cc]) + (p2s[256 + cc] + p2s[384 + cc]);
+            }
+        }
+    }
 }
 
 template <typename T, int OP, int TM, int NW>
@@ -1344,19 +1400,26 @@ __global__ __launch_bounds__(256) void symv_tile_kernel(const T* __restrict__ V,
     if (tid < TS) dst[tid] = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
 }
 
-template <typename T>
+template <typename T, int TZ>
 __global__ __launch_bounds__(256) void symv_reduce_kernel(const double* __restrict__ part, int ntile, int npad, int nb,
                                                           T* __restrict__ z) {
-    // 4 groups of 64 threads take every fourth term; the four partial sums are combined in a fixed order
-    __shared__ double sh[4][TS];
-    const int k = blockIdx.y, R = blockIdx.x, i = threadIdx.x & 63, g = threadIdx.x >> 6;
-    const double* pk = part + (size_t)k * ntile * 2 * TS;
+    // TZ = tile size of the partials (64: symv_tile_kernel, 128: the epilogue of the 128-tile LAUUM); nb in TZ units.
+    // 256 / TZ groups of TZ threads take every NG-th term; the partial sums are combined in a fixed order
+    constexpr int NG = 256 / TZ;
+    __shared__ double sh[NG][TZ];
+    const int k = blockIdx.y, R = blockIdx.x, i = threadIdx.x % TZ, g = threadIdx.x / TZ;
+    const double* pk = part + (size_t)k * ntile * 2 * TZ;
     double s = 0.0;
-    for (int c = g; c <= R; c += 4) s += pk[((size_t)(R * (R + 1) / 2 + c)) * 2 * TS + i];
-    for (int r = R + 1 + g; r < nb; r += 4) s += pk[((size_t)(r * (r + 1) / 2 + R)) * 2 * TS + TS + i];
+    for (int c = g; c <= R; c += NG) s += pk[((size_t)(R * (R + 1) / 2 + c)) * 2 * TZ + i];
+    for (int r = R + 1 + g; r < nb; r += NG) s += pk[((size_t)(r * (r + 1) / 2 + R)) * 2 * TZ + TZ + i];
     sh[g][i] = s;
     __syncthreads();
-    if (g == 0) z[(size_t)k * npad + R * TS + i] = (T)((sh[0][i] + sh[1][i]) + (sh[2][i] + sh[3][i]));
+    if (g == 0) {
+        double v;
+        if constexpr (NG == 4) v = (sh[0][i] + sh[1][i]) + (sh[2][i] + sh[3][i]);
+        else v = sh[0][i] + sh[1][i];
+        z[(size_t)k * npad + R * TZ + i] = (T)v;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -1875,24 +1938,32 @@ int do_trtri(hipStream_t st, const Ws& w, const lcgp_sched& sc) {
 }
 
 template <typename T>
-int do_lauum(hipStream_t st, const Ws& w, const lcgp_sched& sc) {
+int do_lauum(hipStream_t st, const Ws& w, const lcgp_sched& sc, bool* z_partials = nullptr) {
+    // z_partials: the caller also wants z = A^-1 b (b in the workspace).  On 128-tiles the launch leaves the per-tile
+    // partial products in the workspace (epilogue of gemm_body) and sets *z_partials; on 64-tiles it does not.
     GemmArgs g;
     g.sA = g.sB = g.sC = w.mat; g.ldA = g.ldB = g.ldC = w.npad; g.p0 = g.p1 = g.p2 = g.p3 = 0;
     g.A = (T*)(w.base + w.off_W); g.B = g.A; g.C = (T*)(w.base + w.off_V);
+    if (z_partials) *z_partials = false;
     if (use_small_tiles(w, sc.lauum_small_tiles)) {
         g.nb = w.nb;
         return launch_gemm<T, OP_LAUUM, 64>(st, g, w.nb * (w.nb + 1) / 2, w.q);
     }
     const int nb2 = w.nb / 2;
     g.nb = nb2;
+    if (z_partials) {
+        g.bvec = w.base + w.off_b;
+        g.part = (double*)(w.base + w.off_part);
+        *z_partials = true;
+    }
     return launch_gemm<T, OP_LAUUM, 128>(st, g, nb2 * (nb2 + 1) / 2, w.q);
 }
 
 template <typename T>
-int do_potri(hipStream_t st, const Ws& w, const lcgp_sched& sc) {
+int do_potri(hipStream_t st, const Ws& w, const lcgp_sched& sc, bool* z_partials = nullptr) {
     int rc = do_trtri<T>(st, w, sc);
     if (rc) return rc;
-    return do_lauum<T>(st, w, sc);
+    return do_lauum<T>(st, w, sc, z_partials);
 }
 
 template <typename T, int DD>
@@ -1911,13 +1982,20 @@ int do_nll_grad(hipStream_t st, const Ws& w, const lcgp_sched& sc, const void* x
     T* z = (T*)(w.base + w.off_z);
     rc = do_potrf<T>(st, w, sc);
     if (rc) return rc;
-    rc = do_potri<T>(st, w, sc);
+    bool z_partials = false;       // z = A^-1 b: per-tile partials from the 128-tile LAUUM's epilogue, or a pass of its own
+    rc = do_potri<T>(st, w, sc, &z_partials);
     if (rc) return rc;
-    hipLaunchKernelGGL((symv_tile_kernel<T>), dim3(w.ntile_lower, w.q), dim3(256), 0, st, (const T*)(w.base + w.off_V),
-                       w.mat, w.npad, (const T*)b, (double*)(w.base + w.off_part), w.ntile_lower);
-    CHECK_LAUNCH("symv_tile_kernel");
-    hipLaunchKernelGGL((symv_reduce_kernel<T>), dim3(w.nb, w.q), dim3(256), 0, st, (const double*)(w.base + w.off_part),
-                       w.ntile_lower, w.npad, w.nb, z);
+    if (z_partials) {
+        const int nb2 = w.nb / 2;
+        hipLaunchKernelGGL((symv_reduce_kernel<T, 128>), dim3(nb2, w.q), dim3(256), 0, st,
+                           (const double*)(w.base + w.off_part), nb2 * (nb2 + 1) / 2, w.npad, nb2, z);
+    } else {
+        hipLaunchKernelGGL((symv_tile_kernel<T>), dim3(w.ntile_lower, w.q), dim3(256), 0, st, (const T*)(w.base + w.off_V),
+                           w.mat, w.npad, (const T*)b, (double*)(w.base + w.off_part), w.ntile_lower);
+        CHECK_LAUNCH("symv_tile_kernel");
+        hipLaunchKernelGGL((symv_reduce_kernel<T, TS>), dim3(w.nb, w.q), dim3(256), 0, st,
+                           (const double*)(w.base + w.off_part), w.ntile_lower, w.npad, w.nb, z);
+    }
     CHECK_LAUNCH("symv_reduce_kernel");
     if (w.d <= 2) launch_grad<T, 2>(st, w, x, sr, theta);
     else if (w.d <= 4) launch_grad<T, 4>(st, w, x, sr, theta);

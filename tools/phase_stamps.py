@@ -25,6 +25,12 @@ PATCHES = [
     ("    double (*S)[17] = (double (*)[17])scratch;\n    int first_bad = 0;",
      "    double (*S)[17] = (double (*)[17])scratch;\n    int first_bad = 0;\n"
      "    asm volatile(\"s_waitcnt vmcnt(0)\" ::: \"memory\");\n    STAMP(5);"),
+    ("            double dmine = 1.0;                       // the pivot of row li of the diagonal block\n",
+     "            STAMP(22 + 4 * kb);\n            double dmine = 1.0;                       // the pivot of row li of the diagonal block\n"),
+    ("            const double rsl = fast_rsqrt(dmine);     // off the chain\n",
+     "            STAMP(23 + 4 * kb);\n            const double rsl = fast_rsqrt(dmine);     // off the chain\n"),
+    ("            if (lq == 0) { dinv[base + li] = rsl; pivs[base + li] = dmine; }\n",
+     "            STAMP(24 + 4 * kb);\n            if (lq == 0) { dinv[base + li] = rsl; pivs[base + li] = dmine; }\n"),
     ("            if (lane == 0) bad[kb] = first_bad;\n        } else if (wv == kb - 1) {",
      "            if (lane == 0) bad[kb] = first_bad;\n            STAMP(6 + 3 * kb);\n        } else if (wv == kb - 1) {"),
     ("        __syncthreads();\n        if (wv > kb) {", "        __syncthreads();\n        STAMP(7 + 3 * kb);\n        if (wv > kb) {"),
@@ -54,6 +60,9 @@ NAMES = {0: 'start', 1: 'previous column applied', 2: 'L[c+1,c] = tile W_cc^T st
          4: 'diagonal-block routine entered', 5: 'block in registers (from LDS)', 18: 'panels done', 19: 'row 3 of the inverse',
          20: 'last rows of L and W issued', 21: 'log-determinant stored'}
 for _kb in range(4):
+    NAMES[22 + 4 * _kb] = 'panel %d: in chain layout' % _kb
+    NAMES[23 + 4 * _kb] = 'panel %d: 16 pivots done' % _kb
+    NAMES[24 + 4 * _kb] = 'panel %d: scaled' % _kb
     NAMES[6 + 3 * _kb] = 'panel %d factored (wave %d)' % (_kb, _kb)
     NAMES[7 + 3 * _kb] = 'panel %d barrier' % _kb
     NAMES[8 + 3 * _kb] = 'panel %d applied' % _kb
@@ -91,7 +100,7 @@ def run():
     assert lib.lcgp_debug_stamps(out.ctypes.data) == 0
     t0 = int(out[0, 0])
     print('# us since the special workgroup of the last chain step started (100 MHz counter), one column per wave')
-    for s in range(22):
+    for s in range(38):
         row = ['%8.2f' % ((int(out[w, s]) - t0) / 100.0) if out[w, s] else '       -' for w in range(4)]
         print('%2d %-40s %s' % (s, NAMES.get(s, ''), ' '.join(row)))
 
