@@ -520,15 +520,13 @@ __device__ __forceinline__ void leaf_factor_invert(T* __restrict__ Mb, T* __rest
             if (lq == 0) { dinv[base + li] = rsl; pivs[base + li] = dmine; }
             const unsigned long long bm = __ballot(!(dmine > 0.0)) & 0xffffull;
             if (bm) first_bad = jb * TS + base + __ffsll((long long)bm);
-            // lt[col][row]: lane rows 0 .. nlow-1 hold the blocks below the diagonal one, the other kb lane rows write the
-            // zeros of the kb blocks above it; lane row 0 also writes the diagonal block (zero above the diagonal)
-            const int row = lq < nlow ? base + 16 * (1 + lq) + li : 16 * (lq - nlow) + li;
+            // lt[col][row], all 64 rows of the panel's 16 columns in ONE pass of 16 stores: the four lane rows are exactly the
+            // nlow blocks below the diagonal block (lane rows 0 .. nlow-1), the diagonal block itself (lane row nlow: rD is
+            // the same in every lane row; zero above the diagonal) and the kb zero blocks above it (the remaining lane rows)
+            const int row = lq < nlow ? base + 16 * (1 + lq) + li : lq == nlow ? base + li : 16 * (lq - nlow - 1) + li;
 #pragma unroll
-            for (int m = 0; m < 16; ++m) lt[base + m][row] = lq < nlow ? rL[m] : 0.0;
-            if (lq == 0) {
-#pragma unroll
-                for (int m = 0; m < 16; ++m) lt[base + m][base + li] = li >= m ? rD[m] : 0.0;
-            }
+            for (int m = 0; m < 16; ++m)
+                lt[base + m][row] = lq < nlow ? rL[m] : (lq == nlow && li >= m) ? rD[m] : 0.0;
             if (lane == 0) bad[kb] = first_bad;
         } else if (wv == kb - 1) {
             // row kb-1 of the inverse (panel kb-1 and everything it needs became visible at the last barrier)
