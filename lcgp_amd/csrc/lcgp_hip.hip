@@ -1441,11 +1441,13 @@ __global__ __launch_bounds__(256) void grad_kernel(const T* __restrict__ V, size
     const double* th = th_row(theta, d, p, k);
     const double D = th[d + 2];
     const int tid = threadIdx.x;
-    for (int e = tid; e < TS * d; e += 256) {
-        int i = e / d, j = e - i * d;
+    // scaled inputs of the tile's rows and columns; the dimensions d .. DD-1 of the instantiation are zero-filled, so the
+    // loops below run over DD without a test (a zero distance leaves every product and sum unchanged)
+    for (int e = tid; e < TS * DD; e += 256) {
+        int i = e / DD, j = e - i * DD;
         int gi = r * TS + i, gj = c * TS + i;
-        xr[i][j] = gi < n ? (double)x[(size_t)gi * d + j] / th[j] : 0.0;
-        xc[i][j] = gj < n ? (double)x[(size_t)gj * d + j] / th[j] : 0.0;
+        xr[i][j] = (j < d && gi < n) ? (double)x[(size_t)gi * d + j] / th[j] : 0.0;
+        xc[i][j] = (j < d && gj < n) ? (double)x[(size_t)gj * d + j] / th[j] : 0.0;
     }
     if (tid < TS) {
         int gi = r * TS + tid, gj = c * TS + tid;
@@ -1462,11 +1464,26 @@ __global__ __launch_bounds__(256) void grad_kernel(const T* __restrict__ V, size
     // thread = two adjacent columns (one 16-byte load per row in fp64) x 8 rows: two independent chains per load
     const int j0 = (tid & 31) * 2;
     typedef T pair_t __attribute__((ext_vector_type(2)));
+    // all eight rows of the thread are requested up front (the padded matrix has every row of the tile), and the scaled
+    // inputs of its two columns stay in registers when the instantiation is narrow enough
+    pair_t avs[8];
+#pragma unroll
+    for (int m = 0; m < 8; ++m)
+        avs[m] = *(const pair_t*)(Vk + (size_t)(r * TS + (tid >> 5) * 8 + m) * npad + c * TS + j0);
+    constexpr bool HOIST = DD <= 10;
+    double xcv[2][HOIST ? DD : 1];
+    if constexpr (HOIST) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int jj = 0; jj < DD; ++jj) xcv[h][jj] = xc[j0 + h][jj];
+    }
+#pragma unroll
     for (int m = 0; m < 8; ++m) {
         const int i = (tid >> 5) * 8 + m;
         const int gi = r * TS + i;
         if (gi >= n) continue;
-        const pair_t av = *(const pair_t*)(Vk + (size_t)gi * npad + c * TS + j0);
+        const pair_t av = avs[m];
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             const int j = j0 + h;
@@ -1480,7 +1497,9 @@ __global__ __launch_bounds__(256) void grad_kernel(const T* __restrict__ V, size
             double prod = 1.0, ssum = 0.0;
 #pragma unroll
             for (int jj = 0; jj < DD; ++jj) {
-                const double s = jj < d ? fabs(xr[i][jj] - xc[j][jj]) : 0.0;
+                double xcj;
+                if constexpr (HOIST) xcj = xcv[h][jj]; else xcj = xc[j][jj];
+                const double s = fabs(xr[i][jj] - xcj);
                 sv[jj] = s;
                 pre[jj] = prod;
                 prod = fma(prod, s, prod);
