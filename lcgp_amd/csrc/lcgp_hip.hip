@@ -638,9 +638,20 @@ struct GemmArgs {
 // are 4 rows m x 4 k-quads -- without the XOR all four quads of a row hit one bank pair (4-way conflict on every
 // store of every stage; same-box A/B: 11.20 -> 10.95 ms per evaluation).  Within one k row the XOR only permutes each
 // aligned group of 16 columns, so the fragment reads (16 consecutive columns of one row) stay conflict-free, and for
-// the m-contiguous operand layout (KM: 4 consecutive m per lane) it moves whole aligned quads, so the 16-byte stores stay.
-__device__ __forceinline__ constexpr int lds_swz(int k) { return k & 12; }
+// the m-contiguous operand layout (KM: 16-byte pieces per lane) it moves whole aligned pieces, so the 16-byte stores stay.
+// In float the banks are per 4 bytes and a ds_write_b32 group is 32 lanes = 8 rows x 4 k-quads: the XOR constants are
+// 0, 8, 16, 24 there (they exchange whole 16-column groups inside a wave's 32-aligned sub-tile: the read side applies
+// the XOR to the column index relative to the sub-tile origin, which is a multiple of 32).
+template <typename T>
+__device__ __forceinline__ constexpr int lds_swz(int k) { return (k & 12) * (int)(8 / sizeof(T)); }   // float: 0, 8, 16, 24
 static_assert(KT == 16, "lds_swz assumes 16 k rows per stage");
+// Swizzled column of a fragment read: 16-group `g16` (a multiple of 16, compile-time after unrolling) + lane column l15 of
+// k step kk.  The XOR splits into a part that exchanges whole 16-groups (compile-time: folds into the instruction's
+// offset) and a part inside the group (lane-dependent: one register per distinct constant).
+template <typename T>
+__device__ __forceinline__ int swz_col(int g16, int l15, int kk) {
+    return (g16 ^ (lds_swz<T>(4 * kk) & ~15)) + (l15 ^ (lds_swz<T>(4 * kk) & 15));
+}
 
 template <typename T, int L, int TM, int NT>
 __device__ __forceinline__ void load_stage(const T* __restrict__ P, int ld, int ks, T (&reg)[TM * KT / NT], int tid) {
@@ -652,11 +663,17 @@ __device__ __forceinline__ void load_stage(const T* __restrict__ P, int ld, int 
 #pragma unroll
         for (int e = 0; e < EPT; ++e) reg[e] = src[e];
     } else {
+        // a lane holds EPT / PE pieces of 16 bytes; piece p of the lanes of one k row is one contiguous run (so that the
+        // 8-lane groups of the ds_write_b128 that stores it cover 128 contiguous bytes = all 32 banks once; with four
+        // consecutive doubles per lane, lanes l and l + 4 of a group shared their banks: 2-way conflict on every store)
         constexpr int TPK = TM / EPT;                       // threads per k row
-        const int kq = tid / TPK, mm = (tid % TPK) * EPT;
-        const T* src = P + (size_t)(ks + kq) * ld + mm;
+        constexpr int PE = 16 / (int)sizeof(T), NP = EPT / PE;
+        const int kq = tid / TPK, j = tid % TPK;
+        const T* src = P + (size_t)(ks + kq) * ld + j * PE;
 #pragma unroll
-        for (int e = 0; e < EPT; ++e) reg[e] = src[e];
+        for (int pc = 0; pc < NP; ++pc)
+#pragma unroll
+            for (int e = 0; e < PE; ++e) reg[pc * PE + e] = src[pc * (TM / NP) + e];
     }
 }
 
@@ -668,12 +685,15 @@ __device__ __forceinline__ void store_stage(T* __restrict__ S, const T (&reg)[TM
         constexpr int TPR = KT / EPT;
         const int m = tid / TPR, kk = (tid % TPR) * EPT;
 #pragma unroll
-        for (int e = 0; e < EPT; ++e) S[(kk + e) * LD + (m ^ lds_swz(kk + e))] = reg[e];
+        for (int e = 0; e < EPT; ++e) S[(kk + e) * LD + (m ^ lds_swz<T>(kk + e))] = reg[e];
     } else {
         constexpr int TPK = TM / EPT;
-        const int kq = tid / TPK, mm = (tid % TPK) * EPT;
+        constexpr int PE = 16 / (int)sizeof(T), NP = EPT / PE;
+        const int kq = tid / TPK, j = tid % TPK;
 #pragma unroll
-        for (int e = 0; e < EPT; ++e) S[kq * LD + (mm ^ lds_swz(kq)) + e] = reg[e];
+        for (int pc = 0; pc < NP; ++pc)
+#pragma unroll
+            for (int e = 0; e < PE; ++e) S[kq * LD + ((j * PE + pc * (TM / NP)) ^ lds_swz<T>(kq)) + e] = reg[pc * PE + e];
     }
 }
 
@@ -809,11 +829,11 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, const int lin /*blo
             T af[MIM], bf[MIN];
 #pragma unroll
             for (int i = 0; i < MIM; ++i) {
-                const T v = as[krow + wm0 + i * 16 + (l15 ^ lds_swz(4 * kk))];
+                const T v = as[krow + wm0 + swz_col<T>(i * 16, l15, kk)];
                 af[i] = PRELOAD_C ? -v : v;
             }
 #pragma unroll
-            for (int j = 0; j < MIN; ++j) bf[j] = bs[krow + wn0 + j * 16 + (l15 ^ lds_swz(4 * kk))];
+            for (int j = 0; j < MIN; ++j) bf[j] = bs[krow + wn0 + swz_col<T>(j * 16, l15, kk)];
 #pragma unroll
             for (int i = 0; i < MIM; ++i)
 #pragma unroll
@@ -1016,9 +1036,9 @@ __device__ __forceinline__ void syrk_rect_body(const GemmArgs& g, const int lin,
                     const int kr = kk * 4 + (lane >> 4);
                     T af[4], bf[2];
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) af[i] = -as[kr * LDA + wm0 + i * 16 + ((lane & 15) ^ lds_swz(4 * kk))];
+                    for (int i = 0; i < 4; ++i) af[i] = -as[kr * LDA + wm0 + swz_col<T>(i * 16, lane & 15, kk)];
 #pragma unroll
-                    for (int j = 0; j < 2; ++j) bf[j] = bs[kr * LDB + wn0 + j * 16 + ((lane & 15) ^ lds_swz(4 * kk))];
+                    for (int j = 0; j < 2; ++j) bf[j] = bs[kr * LDB + wn0 + swz_col<T>(j * 16, lane & 15, kk)];
 #pragma unroll
                     for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -1141,11 +1161,11 @@ struct Tile64 {          // 64x64 tile on 256 threads: wave (wm, wn) owns a 32x3
                 T af[2], bf[2];
 #pragma unroll
                 for (int i = 0; i < 2; ++i) {
-                    const T v = as[krow + wm0 + i * 16 + ((lane & 15) ^ lds_swz(4 * kk))];
+                    const T v = as[krow + wm0 + swz_col<T>(i * 16, lane & 15, kk)];
                     af[i] = NEG ? -v : v;
                 }
 #pragma unroll
-                for (int j = 0; j < 2; ++j) bf[j] = bs[krow + wn0 + j * 16 + ((lane & 15) ^ lds_swz(4 * kk))];
+                for (int j = 0; j < 2; ++j) bf[j] = bs[krow + wn0 + swz_col<T>(j * 16, lane & 15, kk)];
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -1197,7 +1217,7 @@ struct Tile64 {          // 64x64 tile on 256 threads: wave (wm, wn) owns a 32x3
                     af[i] = NEG ? -v : v;
                 }
 #pragma unroll
-                for (int j = 0; j < 2; ++j) bf[j] = bs[krow + wn0 + j * 16 + ((lane & 15) ^ lds_swz(4 * kk))];
+                for (int j = 0; j < 2; ++j) bf[j] = bs[krow + wn0 + swz_col<T>(j * 16, lane & 15, kk)];
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
