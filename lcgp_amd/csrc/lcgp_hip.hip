@@ -157,7 +157,8 @@ template <typename T, int DD /* >= d: the per-dimension loop is unrolled to DD *
 __global__ __launch_bounds__(256) void build_kernel(T* __restrict__ M, size_t mat, int n, int npad, int d, int p,
                                                     const T* __restrict__ x, const T* __restrict__ sr,
                                                     const double* __restrict__ theta, int ntile,
-                                                    const T* __restrict__ Y, T* __restrict__ bvec) {
+                                                    const T* __restrict__ Y, T* __restrict__ bvec,
+                                                    double* __restrict__ logdet, int* __restrict__ info) {
     // arithmetic in the storage type: the float32 variant is the HBM-bound regime (one float exp per element)
     __shared__ T xr[TS][DD + 1];
     __shared__ T xc[TS][DD + 1];
@@ -167,6 +168,7 @@ __global__ __launch_bounds__(256) void build_kernel(T* __restrict__ M, size_t ma
         // blocks past the tiles: b_k[i] = sum_a Y[a, i] psi_k[a]  (lcgp.py:646 + 657-658 collapsed; 608-610 for rep),
         // independent of the matrix, so it rides in this launch instead of a launch of its own
         const int i = (blockIdx.x - ntile) * 256 + threadIdx.x;
+        if (i == 0 && logdet) { logdet[k] = 0.0; info[k] = 0; }      // the factorisation that follows starts from zero
         if (i >= npad) return;
         const double* psi = th_row(theta, d, p, k) + d + 3;
         double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
@@ -725,8 +727,23 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, const int lin /*blo
 
     // (tile, component) with the component as the FAST index: tiles are enumerated heaviest first, so the heaviest
     // tiles of every component start at once instead of component by component
-    const int k = lin % g.q;
-    const int bid = lin / g.q;
+    int lin_ = lin;
+    if constexpr (OP == OP_TRTRI_T || OP == OP_TRTRI_W || OP == OP_LAUUM) {
+        // With few components a launch of the triangular products is one or two rounds of resident workgroups, so its
+        // time is the k length a CU collects from the tiles it hosts together.  Workgroups go to the CUs round-robin
+        // (workgroup b and b + 256 share a CU): every other group of 256 is enumerated backwards, which pairs the
+        // heaviest tiles with the lightest ones (first round at n = 4096, one component: 80 k tiles on the fullest CU
+        // in plain heaviest-first order, 66 on every CU this way; same-box A/B: 2.80 -> 2.73 ms at one component, 3.93 ->
+        // 3.91 at two, nothing at four).  With many components the launches have many rounds, and with 8 the component
+        // index doubles as the XCD index (L2 locality), which the reversal would break.
+        if (g.q < 4 && ((lin >> 8) & 1)) {
+            const int base = lin & ~255, nblk = (int)gridDim.x;
+            const int top = base + 255 < nblk ? base + 255 : nblk - 1;      // last index of this (possibly short) group
+            lin_ = top - (lin - base);
+        }
+    }
+    const int k = lin_ % g.q;
+    const int bid = lin_ / g.q;
     const T* Ab = (const T*)g.A + (size_t)k * g.sA;
     const T* Bb = (const T*)g.B + (size_t)k * g.sB;
     T* Cb = (T*)g.C + (size_t)k * g.sC;
@@ -1446,11 +1463,42 @@ __global__ __launch_bounds__(256) void symv_reduce_kernel(const double* __restri
 //   part[0..d-1] = sum w G C0 S_j^2/(1+S_j),  part[d] = sum w G C0,  part[d+1] = sum_i G_ii
 // C0 and S_j are recomputed from x in LDS.  Per-tile partial sums, reduced later in fixed order.
 // ---------------------------------------------------------------------------------------------------
+// ---------------------------------------------------------------------------------------------------
+// finalize: per component, reduce the tile partials, quad = b.(b - z), pack output (gsig_a = Y[a,:].(b - z): gsig_body).
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double block_sum(double v, double* sh /*>= 4*/, int tid) {
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    __syncthreads();
+    if ((tid & 63) == 0) sh[tid >> 6] = v;
+    __syncthreads();
+    return (sh[0] + sh[1]) + (sh[2] + sh[3]);
+}
+
+// gsig_a = sum_i Y[a, i] (b_i - z_i): one workgroup per (output a, component); rides in the launch of the gradient
+// contraction (blocks past the tiles), like b in the kernel-build launch
+template <typename T>
+__device__ __forceinline__ void gsig_body(int a, int k, int n, int npad, int d, int p, const T* __restrict__ Y,
+                                          const T* __restrict__ b, const T* __restrict__ z, double* __restrict__ out) {
+    __shared__ double sh[4];
+    const int tid = threadIdx.x;
+    const T* bk = b + (size_t)k * npad;
+    const T* zk = z + (size_t)k * npad;
+    double s = 0.0;
+    for (int i = tid; i < n; i += 256) s += (double)Y[(size_t)a * n + i] * ((double)bk[i] - (double)zk[i]);
+    s = block_sum(s, sh, tid);
+    if (tid == 0) out[(size_t)k * (d + 5 + p) + 5 + d + a] = s;
+}
+
 template <typename T, int DD>
 __global__ __launch_bounds__(256) void grad_kernel(const T* __restrict__ V, size_t mat, int n, int npad, int d, int p,
                                                    const T* __restrict__ x, const T* __restrict__ sr,
                                                    const T* __restrict__ z, const double* __restrict__ theta,
-                                                   double* __restrict__ part, int ntile) {
+                                                   double* __restrict__ part, int ntile, const T* __restrict__ Y,
+                                                   const T* __restrict__ bvec, double* __restrict__ out) {
+    if ((int)blockIdx.x >= ntile) {
+        gsig_body<T>(blockIdx.x - ntile, blockIdx.y, n, npad, d, p, Y, bvec, z, out);
+        return;
+    }
     __shared__ double xr[TS][DD + 1];
     __shared__ double xc[TS][DD + 1];
     __shared__ double zr[TS], zc[TS], srr[TS], src[TS];
@@ -1554,16 +1602,6 @@ __global__ __launch_bounds__(256) void grad_kernel(const T* __restrict__ V, size
     }
 }
 
-// ---------------------------------------------------------------------------------------------------
-// finalize: per component, reduce the tile partials, quad = b.(b - z), gsig_a = Y[a,:].(b - z), pack output.
-// ---------------------------------------------------------------------------------------------------
-__device__ __forceinline__ double block_sum(double v, double* sh /*>= 4*/, int tid) {
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
-    __syncthreads();
-    if ((tid & 63) == 0) sh[tid >> 6] = v;
-    __syncthreads();
-    return (sh[0] + sh[1]) + (sh[2] + sh[3]);
-}
 
 template <typename T>
 __global__ __launch_bounds__(256) void finalize_kernel(int n, int npad, int d, int p, int ntile,
@@ -1622,20 +1660,6 @@ __global__ __launch_bounds__(256) void finalize_kernel(int n, int npad, int d, i
     }
 }
 
-// gsig_a = sum_i Y[a, i] (b_i - z_i): one workgroup per (output a, component)
-template <typename T>
-__global__ __launch_bounds__(256) void gsig_kernel(int n, int npad, int d, int p, const T* __restrict__ Y,
-                                                   const T* __restrict__ b, const T* __restrict__ z,
-                                                   double* __restrict__ out) {
-    __shared__ double sh[4];
-    const int a = blockIdx.x, k = blockIdx.y, tid = threadIdx.x;
-    const T* bk = b + (size_t)k * npad;
-    const T* zk = z + (size_t)k * npad;
-    double s = 0.0;
-    for (int i = tid; i < n; i += 256) s += (double)Y[(size_t)a * n + i] * ((double)bk[i] - (double)zk[i]);
-    s = block_sum(s, sh, tid);
-    if (tid == 0) out[(size_t)k * (d + 5 + p) + 5 + d + a] = s;
-}
 
 // small helpers ----------------------------------------------------------------------------------------
 __global__ void zero_stats_kernel(double* logdet, int* info, int q) {
@@ -1688,8 +1712,10 @@ __global__ __launch_bounds__(64) void pred_reduce_kernel(const T* __restrict__ X
 
 template <typename T, int DD>
 void launch_build(hipStream_t st, const Ws& w, dim3 grid, const void* x, const void* sr, const double* theta, const void* Y) {
+    // with Y (the NLL path) the launch also zeroes the log-determinant and status words of the components
     hipLaunchKernelGGL((build_kernel<T, DD>), grid, dim3(256), 0, st, (T*)(w.base + w.off_M), w.mat, w.n, w.npad, w.d, w.p,
-                       (const T*)x, (const T*)sr, theta, w.ntile_lower, (const T*)Y, (T*)(w.base + w.off_b));
+                       (const T*)x, (const T*)sr, theta, w.ntile_lower, (const T*)Y, (T*)(w.base + w.off_b),
+                       Y ? (double*)(w.base + w.off_logdet) : nullptr, Y ? (int*)(w.base + w.off_info) : nullptr);
 }
 
 template <typename T>
@@ -1868,11 +1894,13 @@ int potrf_trailing(hipStream_t st, const Ws& w, const lcgp_sched& sc, int J, int
 // launches of panel J+1 carry as filler tiles -- the chain leaves >= 97 % of the CUs idle, and a second HIP stream
 // cannot fill them on this platform.
 template <typename T>
-int do_potrf(hipStream_t st, const Ws& w, const lcgp_sched& sc) {
+int do_potrf(hipStream_t st, const Ws& w, const lcgp_sched& sc, bool stats_zeroed = false) {
     double* logdet = (double*)(w.base + w.off_logdet);
     int* info = (int*)(w.base + w.off_info);
-    hipLaunchKernelGGL(zero_stats_kernel, dim3((w.q + 63) / 64), dim3(64), 0, st, logdet, info, w.q);
-    CHECK_LAUNCH("zero_stats");
+    if (!stats_zeroed) {       // (the NLL path's kernel-build launch has done it)
+        hipLaunchKernelGGL(zero_stats_kernel, dim3((w.q + 63) / 64), dim3(64), 0, st, logdet, info, w.q);
+        CHECK_LAUNCH("zero_stats");
+    }
     const int ob = sc.outer_blocks < 1 ? (sizeof(T) == 4 ? 8 : 4) : sc.outer_blocks;
     const bool t128 = (ob & 1) == 0;
     Filler fill;
@@ -2004,10 +2032,12 @@ int do_potri(hipStream_t st, const Ws& w, const lcgp_sched& sc, bool* z_partials
 }
 
 template <typename T, int DD>
-void launch_grad(hipStream_t st, const Ws& w, const void* x, const void* sr, const double* theta) {
-    hipLaunchKernelGGL((grad_kernel<T, DD>), dim3(w.ntile_lower, w.q), dim3(256), 0, st, (const T*)(w.base + w.off_V),
-                       w.mat, w.n, w.npad, w.d, w.p, (const T*)x, (const T*)sr, (const T*)(w.base + w.off_z), theta,
-                       (double*)(w.base + w.off_part), w.ntile_lower);
+void launch_grad(hipStream_t st, const Ws& w, const void* x, const void* sr, const double* theta, const void* Y,
+                 double* out) {
+    hipLaunchKernelGGL((grad_kernel<T, DD>), dim3(w.ntile_lower + w.p, w.q), dim3(256), 0, st,
+                       (const T*)(w.base + w.off_V), w.mat, w.n, w.npad, w.d, w.p, (const T*)x, (const T*)sr,
+                       (const T*)(w.base + w.off_z), theta, (double*)(w.base + w.off_part), w.ntile_lower, (const T*)Y,
+                       (const T*)(w.base + w.off_b), out);
 }
 
 template <typename T>
@@ -2017,7 +2047,7 @@ int do_nll_grad(hipStream_t st, const Ws& w, const lcgp_sched& sc, const void* x
     if (rc) return rc;
     T* b = (T*)(w.base + w.off_b);
     T* z = (T*)(w.base + w.off_z);
-    rc = do_potrf<T>(st, w, sc);
+    rc = do_potrf<T>(st, w, sc, true);
     if (rc) return rc;
     bool z_partials = false;       // z = A^-1 b: per-tile partials from the 128-tile LAUUM's epilogue, or a pass of its own
     rc = do_potri<T>(st, w, sc, &z_partials);
@@ -2034,20 +2064,17 @@ int do_nll_grad(hipStream_t st, const Ws& w, const lcgp_sched& sc, const void* x
                            (const double*)(w.base + w.off_part), w.ntile_lower, w.npad, w.nb, z);
     }
     CHECK_LAUNCH("symv_reduce_kernel");
-    if (w.d <= 2) launch_grad<T, 2>(st, w, x, sr, theta);
-    else if (w.d <= 4) launch_grad<T, 4>(st, w, x, sr, theta);
-    else if (w.d <= 6) launch_grad<T, 6>(st, w, x, sr, theta);
-    else if (w.d <= 10) launch_grad<T, 10>(st, w, x, sr, theta);
-    else if (w.d <= 16) launch_grad<T, 16>(st, w, x, sr, theta);
-    else launch_grad<T, DMAX>(st, w, x, sr, theta);
+    if (w.d <= 2) launch_grad<T, 2>(st, w, x, sr, theta, Y, out);
+    else if (w.d <= 4) launch_grad<T, 4>(st, w, x, sr, theta, Y, out);
+    else if (w.d <= 6) launch_grad<T, 6>(st, w, x, sr, theta, Y, out);
+    else if (w.d <= 10) launch_grad<T, 10>(st, w, x, sr, theta, Y, out);
+    else if (w.d <= 16) launch_grad<T, 16>(st, w, x, sr, theta, Y, out);
+    else launch_grad<T, DMAX>(st, w, x, sr, theta, Y, out);
     CHECK_LAUNCH("grad_kernel");
     hipLaunchKernelGGL((finalize_kernel<T>), dim3(w.q), dim3(256), 0, st, w.n, w.npad, w.d, w.p, w.ntile_lower,
                        (const T*)Y, (const T*)b, (const T*)z, (const double*)(w.base + w.off_part),
                        (const double*)(w.base + w.off_logdet), (const int*)(w.base + w.off_info), theta, out);
     CHECK_LAUNCH("finalize_kernel");
-    hipLaunchKernelGGL((gsig_kernel<T>), dim3(w.p, w.q), dim3(256), 0, st, w.n, w.npad, w.d, w.p, (const T*)Y, (const T*)b,
-                       (const T*)z, out);
-    CHECK_LAUNCH("gsig_kernel");
     return 0;
 }
 
