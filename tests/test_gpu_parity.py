@@ -236,6 +236,42 @@ def test_cfg3_inverse_times_matrix_is_identity_on_sampled_columns(cfg3):
     assert np.max(np.abs(ident - want)) < 1e-9
 
 
+def test_few_components_many_tiles_inverse_and_derivative():
+    """One rank's share of a multi-GPU run: q_local = 2 at n = 2304 (a ragged 128-tile edge).  With fewer than 4
+    components the tiles of the triangular products are enumerated in a different order (every other group of 256
+    backwards, lcgp_hip.hip gemm_body) once a launch has more than 256 of them, which only sizes like this reach:
+    A^-1 A = I on sampled columns of both components and the directional derivative of the NLL check the inverse and
+    everything downstream of it without an O(n^3) CPU oracle."""
+    x, y = synth.make_full(77, 2304, 3, 5, 2)
+    m = LCGP(y=y, x=x, q=2)
+    u = synth.param_points(77, m._get_flat())[1]
+    v0, g = m.loss_and_grad(u)
+    assert np.isfinite(v0) and np.all(np.isfinite(g))
+    lLmb, lLmb0, _, lnug = (t.numpy() for t in m.get_param())
+    cols = [0, 63, 64, 127, 128, 1151, 1152, 2240, 2303]
+    for k in range(2):
+        ainv = m._engine.fetch_matrix(2, k)
+        ck = orc.matern32(m.x.numpy(), m.x.numpy()[cols], lLmb[k], lLmb0[k], lnug[k])
+        nt = lnug[k] / (1 + lnug[k])
+        acols = m.diag_D.numpy()[k] * ck
+        for j, c in enumerate(cols):
+            acols[c, j] += 1.0 + m.diag_D.numpy()[k] * lLmb0[k] * nt
+        ident = ainv @ acols
+        for j, c in enumerate(cols):
+            ident[c, j] -= 1.0
+        assert np.max(np.abs(ident)) < 1e-9, (k, np.max(np.abs(ident)))
+    rng = np.random.default_rng(77)
+    dirn = rng.standard_normal(u.shape)
+    dirn /= np.linalg.norm(dirn)
+    h = 1e-5
+    vp, _ = m.loss_and_grad(u + h * dirn)
+    vm, _ = m.loss_and_grad(u - h * dirn)
+    fd = (vp - vm) / (2 * h)
+    assert abs(fd - g @ dirn) <= 1e-5 * max(1.0, abs(g @ dirn)), (fd, g @ dirn)
+    v1, g1 = m.loss_and_grad(u)
+    assert v1 == v0 and np.array_equal(g1, g)
+
+
 def test_cfg3_nll_matches_oracle(cfg3):
     x, y, cfg, m = cfg3
     o = orc.OracleLCGP(y=y, x=x, q=cfg['q'])
