@@ -429,9 +429,13 @@ class LCGP:
         n, d, p, q = int(self.n), int(self.d), int(self.p), int(self.q)
         es = np.asarray(self.diag_error_structure, int)
         ls2_b = np.repeat(self.lsigma2s.numpy(), es)
-        sig_eff = np.exp(0.5 * ls2_b) / self._std
+        # a line-search trial may push lsigma2s far out: exp() overflowing to inf (psi / inf = 0) gives a huge finite value
+        # that the optimiser rejects, as it does in the reference -- without numpy's warnings
+        with np.errstate(over='ignore', divide='ignore'):
+            sig_eff = np.exp(0.5 * ls2_b) / self._std
+            rows = self._theta_rows(sig_eff) if eng is not None else None
         if eng is not None:
-            part = eng.evaluate_partial(self._theta_rows(sig_eff))
+            part = eng.evaluate_partial(rows)
         else:
             part = self._zeros_on_device(2 + q * d + 2 * q + p)
         vec = _dist.reduce_to_host(part, self._group)
