@@ -259,7 +259,8 @@ def main():
                 traffic = tj.get('tile_gemm_lauum_bytes_per_launch')
         except Exception:
             pass
-        out['roofline'] = dict(bound='mfma', kernel='tile_gemm<double, OP_LAUUM> (A^-1 = W^T W, one launch per evaluation)',
+        out['roofline'] = dict(bound='mfma', kernel='tile_gemm<double, OP_LAUUM> (A^-1 = W^T W with z = A^-1 b in its epilogue, one launch per evaluation; '
+                                                    'lcgp_lauum enqueues the same launch)',
                                achieved=fl / (st['lauum'] * 1e-3) / 1e12, peak=peak, unit='TFLOP/s',
                                frac=fl / (st['lauum'] * 1e-3) / 1e12 / peak, traffic=traffic,
                                flops_per_launch=fl, launch_ms=st['lauum'])

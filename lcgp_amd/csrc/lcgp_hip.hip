@@ -2016,11 +2016,11 @@ int do_lauum(hipStream_t st, const Ws& w, const lcgp_sched& sc, bool* z_partials
     }
     const int nb2 = w.nb / 2;
     g.nb = nb2;
-    if (z_partials) {
-        g.bvec = w.base + w.off_b;
-        g.part = (double*)(w.base + w.off_part);
-        *z_partials = true;
-    }
+    // the epilogue runs in every 128-tile launch, also when only A^-1 is asked for (lcgp_lauum / lcgp_potri: b in the
+    // workspace may then be stale and the partials are never read): one launch shape to measure and to maintain
+    g.bvec = w.base + w.off_b;
+    g.part = (double*)(w.base + w.off_part);
+    if (z_partials) *z_partials = true;
     return launch_gemm<T, OP_LAUUM, 128>(st, g, nb2 * (nb2 + 1) / 2, w.q);
 }
 
