@@ -754,6 +754,7 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, const int lin /*blo
     int nkt;
     double alpha = 1.0;
     bool accumulate = false;
+    bool tri_b = false;         // OP_LAUUM: the B operand of the last k tile is triangular too (diagonal tile)
     if constexpr (OP == OP_SYRK) {
         // M[r, c] -= sum_{kt in [p0, p1)} M[r, kt] M[c, kt]^T over the tiles c in [p2, p3), r in [c, nb)
         // (p3 == nb: the whole trailing triangle; p3 < nb: the rest of the current panel), column-major
@@ -800,6 +801,7 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, const int lin /*blo
         A0 = Ab + (size_t)(g.nb - 1) * TM * g.ldA + (size_t)r * TM; dA = -(ptrdiff_t)TM * g.ldA;
         B0 = Bb + (size_t)(g.nb - 1) * TM * g.ldB + (size_t)c * TM; dB = -(ptrdiff_t)TM * g.ldB;
         nkt = g.nb - r;
+        tri_b = r == c;
         Ct = Cb + (size_t)r * TM * g.ldC + (size_t)c * TM;
     } else {
         // OP_PRED_U: U[m, r] = sum_{kt = 0}^{r} X[m, kt] W[r, kt]^T    (X = scaled cross covariance, n0pad x npad)
@@ -836,6 +838,21 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, const int lin /*blo
 
     constexpr int SPT = TM / KT;   // stages per k tile
     const int nst = nkt * SPT;
+    // The LAST k tile of the triangular products holds a triangular TM x TM block of W (LAUUM: W[r,r] as A, and as B too
+    // on a diagonal tile; TRTRI_T: W11[cl,cl] as B; TRTRI_W: W22[rl,rl] as A; PRED_U: W[r,r] as B).  In the stage that
+    // covers its k rows [ks, ks + 16) a wave whose rows (columns) of that operand lie wholly on the zero side would
+    // only add exact zeros: it skips the stage's fragment reads and MFMAs (one wave-uniform test per stage, nothing
+    // else changes; bit-identical results: the zeros are stored zeros).  LAUUM / TRTRI_W: 24 of the 64 (wave, stage)
+    // pairs of such a tile, TRTRI_T / PRED_U: 16.
+    constexpr bool HAS_TRI = OP != OP_SYRK;
+    const int tri_first = HAS_TRI ? (nkt - 1) * SPT : nst;
+    // the wave is idle in the stages [dead_lo, dead_hi) of the k loop (two scalars per wave)
+    int dead_lo = nst, dead_hi = nst;
+    if constexpr (OP == OP_LAUUM) { dead_lo = tri_first; dead_hi = tri_first + (tri_b && wn0 > wm0 ? wn0 : wm0) / KT; }
+    else if constexpr (OP == OP_TRTRI_T) { dead_lo = tri_first; dead_hi = tri_first + wn0 / KT; }
+    else if constexpr (OP == OP_TRTRI_W) dead_lo = tri_first + (wm0 + WTM) / KT;
+    else if constexpr (OP == OP_PRED_U) dead_lo = tri_first + (wn0 + WTN) / KT;
+    auto wave_live = [&](int sg) { return !HAS_TRI || sg < dead_lo || sg >= dead_hi; };
     auto compute_stage = [&](int buf) {
         const T* as = As + buf * KT * LD;
         const T* bs = Bs + buf * KT * LD;
@@ -873,7 +890,7 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, const int lin /*blo
                 store_stage<T, LA, TM, NT>(As + (s & 1) * KT * LD, pa[s], tid);
                 store_stage<T, LB, TM, NT>(Bs + (s & 1) * KT * LD, pb[s], tid);
                 __syncthreads();
-                compute_stage(s & 1);
+                if (wave_live(s)) compute_stage(s & 1);
             }
             done = true;
         }
@@ -909,7 +926,7 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, const int lin /*blo
                         load_stage<T, LA, TM, NT>(A0 + (ptrdiff_t)kt * dA, g.ldA, ks, ra[h], tid);
                         load_stage<T, LB, TM, NT>(B0 + (ptrdiff_t)kt * dB, g.ldB, ks, rb[h], tid);
                     }
-                    compute_stage(buf);
+                    if (wave_live(s + h)) compute_stage(buf);
                 }
             }
         }
