@@ -6,13 +6,14 @@ CXXFLAGS = -O3 -std=c++17 --offload-arch=$(ARCH)
 LIB = lcgp_amd/liblcgp_hip.so
 SRC = lcgp_amd/csrc/lcgp_hip.hip
 HDR = include/lcgp_hip.h
+SCHED = lcgp_amd/csrc/fill_sched.h
 # the same digest lcgp_amd/_hip.py::source_hash() computes: the binary carries it (lcgp_source_hash()), so a
 # stale library is detected by content, not by mtime
-HASH = $(shell cat $(SRC) $(HDR) | sha256sum | cut -c1-16)
+HASH = $(shell cat $(SRC) $(HDR) $(SCHED) | sha256sum | cut -c1-16)
 
 all: $(LIB) tests/native/test_kernels
 
-$(LIB): $(SRC) $(HDR)
+$(LIB): $(SRC) $(HDR) $(SCHED)
 	$(HIPCC) $(CXXFLAGS) -fPIC -shared '-DLCGP_SRC_HASH="LCGP_SRC_HASH=$(HASH)"' -o $@ $(SRC)
 
 tests/native/test_kernels: tests/native/test_kernels.cpp $(LIB) $(HDR)

@@ -73,6 +73,12 @@ typedef struct lcgp_sched {
     int fill_step;          /* filler blocks carried by a chain-step launch that ends in a diagonal block (248) */
     int leaf_in_wide;       /* a trailing update of at most this many 64x64 tiles also factors the next panel's first
                                diagonal block, so that panel's chain starts one launch earlier (1024; 0 = never) */
+    int progressive_tiles;  /* lcgp_nll_grad only: with at most this many 128x128 lower tiles x components (few components
+                               per rank) L^-1 and A^-1 are formed panel by panel BEHIND the factorisation, as filler tiles
+                               of the chain launches, instead of after it (600; 0 = never) */
+    int progressive_far;    /* with the progressive inverse: 1 = the far columns of a trailing update still ride on the next
+                               panel's chain launches, 0 = every trailing update is one wide launch (the chain launches
+                               carry the jobs of the inverse only) */
 } lcgp_sched;
 int lcgp_sched_default(lcgp_sched* sched /*host out*/);
 

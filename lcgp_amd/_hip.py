@@ -14,6 +14,7 @@ _ROOT = os.path.dirname(_HERE)
 LIB_PATH = os.path.join(_HERE, "liblcgp_hip.so")
 SRC_PATH = os.path.join(_HERE, "csrc", "lcgp_hip.hip")
 HDR_PATH = os.path.join(_ROOT, "include", "lcgp_hip.h")
+SCHED_PATH = os.path.join(_HERE, "csrc", "fill_sched.h")
 
 F64, F32 = 0, 1
 
@@ -22,7 +23,7 @@ class Sched(C.Structure):
     """lcgp_sched of include/lcgp_hip.h: launch shapes of the factorisation / inverse, passed per call."""
     _fields_ = [("outer_blocks", C.c_int), ("syrk_small_tiles", C.c_int), ("trtri_small_tiles", C.c_int),
                 ("lauum_small_tiles", C.c_int), ("trtri_level_small", C.c_int), ("fill_leaf", C.c_int),
-                ("fill_step", C.c_int), ("leaf_in_wide", C.c_int)]
+                ("fill_step", C.c_int), ("leaf_in_wide", C.c_int), ("progressive_tiles", C.c_int), ("progressive_far", C.c_int)]
 
 
 # every symbol include/lcgp_hip.h declares: name -> (restype, argtypes)
@@ -59,7 +60,7 @@ def source_hash() -> str:
     LCGP_SRC_HASH and returned by lcgp_source_hash(), so source and binary can be compared on any box."""
     import hashlib
     h = hashlib.sha256()
-    for path in (SRC_PATH, HDR_PATH):
+    for path in (SRC_PATH, HDR_PATH, SCHED_PATH):
         with open(path, "rb") as f:
             h.update(f.read())
     return h.hexdigest()[:16]

@@ -19,6 +19,7 @@
 #include <math.h>
 
 #include "../../include/lcgp_hip.h"
+#include "fill_sched.h"
 
 #define LCGP_VERSION 200
 
@@ -736,7 +737,7 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, const int lin /*blo
         // in plain heaviest-first order, 66 on every CU this way; same-box A/B: 2.80 -> 2.73 ms at one component, 3.93 ->
         // 3.91 at two, nothing at four).  With many components the launches have many rounds, and with 8 the component
         // index doubles as the XCD index (L2 locality), which the reversal would break.
-        if (g.q < 4 && ((lin >> 8) & 1)) {
+        if (g.q < 4 && !g.skipq && ((lin >> 8) & 1)) {      // (skipq: the body runs as a filler job, gridDim is not its own)
             const int base = lin & ~255, nblk = (int)gridDim.x;
             const int top = base + 255 < nblk ? base + 255 : nblk - 1;      // last index of this (possibly short) group
             lin_ = top - (lin - base);
@@ -772,7 +773,7 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, const int lin /*blo
         // fastest one) so that the long tiles start early and the short ones fill the tail.
         const int mb = g.p0;
         const int npair = g.p1;
-        const int pr = bid % npair, rem = bid / npair;
+        const int pr = g.p2 + bid % npair, rem = bid / npair;      // p2 = first pair (0 for a whole level)
         int rl, cl;
         if constexpr (OP == OP_TRTRI_T) { cl = rem / mb; rl = rem - cl * mb; }
         else { rl = mb - 1 - rem / mb; cl = rem % mb; }
@@ -1013,56 +1014,69 @@ __global__ __launch_bounds__(NW * 64, TM == 128 ? (NW == 8 ? 4 : 2) : 4) void ti
     gemm_body<T, OP, TM, NW>(g, blockIdx.x, lds);
 }
 
-// Rectangular variant of the trailing update for FILLER work: 128 x 64 tiles on 4 waves (64 x 32 per wave, 4x2
-// accumulators).  A filler workgroup shares its launch with the diagonal-block kernel, i.e. 256 threads and two
-// workgroups per CU; a 64x64 tile then leaves the MFMA pipe half idle, this shape fills it (same K loop, twice
-// the flops per workgroup, 57 KB of LDS).  Tiles: 64-wide column c (from g.p2 to g.nb, 64-units), 128-row blocks R
-// from c/2 down to the last; K = the 64-blocks [g.p0, g.p1).  C -= A B^T with C preloaded into the accumulators.
-template <typename T>
-__device__ __forceinline__ void syrk_rect_body(const GemmArgs& g, const int lin, unsigned char* lds) {
+// ---------------------------------------------------------------------------------------------------
+// Filler tiles (fill_sched.h): 128 x 64 outputs on 4 waves (64 x 32 per wave, 4x2 accumulators), K = nst stages of 16.
+// A filler workgroup shares its launch with the diagonal-block kernel, i.e. 256 threads and two workgroups per CU; a
+// 64x64 tile then leaves the MFMA pipe half idle, this shape fills it (57 KB of LDS).  Operands in either orientation
+// (MK: element (m, k) at P[m ld + k];  KM: at P[k ld + m]); C = (first ? 0 : C) +- A B^T(-like) product.
+// ---------------------------------------------------------------------------------------------------
+using lcgp_fill::FillJob;
+using lcgp_fill::FillSet;
+
+template <typename T, int LA, int LB, bool NEG>
+__device__ __forceinline__ void rect_tile(const T* __restrict__ A0, int ldA, const T* __restrict__ B0, int ldB,
+                                          T* __restrict__ Ct, int ldC, int nst, bool first, unsigned char* lds) {
     constexpr int TMR = 128, TNC = 64, NT = 256;
     constexpr int LDA = TMR + 16, LDB = TNC + 16;
     constexpr int EA = TMR * KT / NT, EB = TNC * KT / NT;
     T* As = (T*)lds;                   // [2][KT * LDA]
     T* Bs = As + 2 * KT * LDA;         // [2][KT * LDB]
-    const int k = lin % g.q;
-    int t = lin / g.q + g.t0, c = g.p2;
-    const int nb2 = g.nb / 2;
-    while (t >= nb2 - (c >> 1)) { t -= nb2 - (c >> 1); ++c; }
-    const int R = (c >> 1) + t;
-    const T* A0 = (const T*)g.A + (size_t)k * g.sA + (size_t)R * TMR * g.ldA + (size_t)g.p0 * TS;
-    const T* B0 = (const T*)g.B + (size_t)k * g.sB + (size_t)c * TNC * g.ldB + (size_t)g.p0 * TS;
-    T* Ct = (T*)g.C + (size_t)k * g.sC + (size_t)R * TMR * g.ldC + (size_t)c * TNC;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm0 = (wave >> 1) * 64, wn0 = (wave & 1) * 32;
     typedef typename Mfma<T>::acc_t acc_t;
     acc_t acc[4][2];
+    if (first) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+            for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int e = 0; e < 4; ++e)
-                acc[i][j][e] = Ct[(size_t)(wm0 + i * 16 + Mfma<T>::row(lane, e)) * g.ldC + wn0 + j * 16 + (lane & 15)];
-    const int nst = (g.p1 - g.p0) * (TS / KT);
+                for (int e = 0; e < 4; ++e) acc[i][j][e] = 0;
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    acc[i][j][e] = Ct[(size_t)(wm0 + i * 16 + Mfma<T>::row(lane, e)) * ldC + wn0 + j * 16 + (lane & 15)];
+    }
+    // Software pipeline over the K stages, one barrier per stage: while the MFMAs of stage s run from LDS buffer s & 1, the
+    // registers of stage s + 1 are written to the other buffer (last read in stage s - 1, i.e. before the previous
+    // barrier) and the global loads of stage s + 3 are issued.  A filler workgroup is alone on its SIMDs (one wave
+    // each), so nothing else hides the LDS writes: issued behind the MFMAs of the same stage they cost 0.4 us per stage.
     T ra[2][EA], rb[2][EB];
-    load_stage<T, MK, TMR, NT>(A0, g.ldA, 0, ra[0], tid);
-    load_stage<T, MK, TNC, NT>(B0, g.ldB, 0, rb[0], tid);
+    if (nst > 0) {
+        load_stage<T, LA, TMR, NT>(A0, ldA, 0, ra[0], tid);
+        load_stage<T, LB, TNC, NT>(B0, ldB, 0, rb[0], tid);
+    }
     if (nst > 1) {
-        load_stage<T, MK, TMR, NT>(A0, g.ldA, KT, ra[1], tid);
-        load_stage<T, MK, TNC, NT>(B0, g.ldB, KT, rb[1], tid);
+        load_stage<T, LA, TMR, NT>(A0, ldA, KT, ra[1], tid);
+        load_stage<T, LB, TNC, NT>(B0, ldB, KT, rb[1], tid);
+    }
+    if (nst > 0) {
+        store_stage<T, LA, TMR, NT>(As, ra[0], tid);
+        store_stage<T, LB, TNC, NT>(Bs, rb[0], tid);
+        if (nst > 2) {
+            load_stage<T, LA, TMR, NT>(A0, ldA, 2 * KT, ra[0], tid);
+            load_stage<T, LB, TNC, NT>(B0, ldB, 2 * KT, rb[0], tid);
+        }
+        __syncthreads();
     }
     for (int s = 0; s < nst; s += 2) {
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             if (s + h < nst) {
-                store_stage<T, MK, TMR, NT>(As + h * KT * LDA, ra[h], tid);
-                store_stage<T, MK, TNC, NT>(Bs + h * KT * LDB, rb[h], tid);
-                __syncthreads();
-                if (s + h + 2 < nst) {
-                    load_stage<T, MK, TMR, NT>(A0, g.ldA, (s + h + 2) * KT, ra[h], tid);
-                    load_stage<T, MK, TNC, NT>(B0, g.ldB, (s + h + 2) * KT, rb[h], tid);
-                }
                 const T* as = As + h * KT * LDA;
                 const T* bs = Bs + h * KT * LDB;
 #pragma unroll
@@ -1070,14 +1084,27 @@ __device__ __forceinline__ void syrk_rect_body(const GemmArgs& g, const int lin,
                     const int kr = kk * 4 + (lane >> 4);
                     T af[4], bf[2];
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) af[i] = -as[kr * LDA + wm0 + swz_col<T>(i * 16, lane & 15, kk)];
+                    for (int i = 0; i < 4; ++i) {
+                        const T v = as[kr * LDA + wm0 + swz_col<T>(i * 16, lane & 15, kk)];
+                        af[i] = NEG ? -v : v;
+                    }
 #pragma unroll
                     for (int j = 0; j < 2; ++j) bf[j] = bs[kr * LDB + wn0 + swz_col<T>(j * 16, lane & 15, kk)];
 #pragma unroll
                     for (int i = 0; i < 4; ++i)
 #pragma unroll
                         for (int j = 0; j < 2; ++j) acc[i][j] = Mfma<T>::run(af[i], bf[j], acc[i][j]);
+                    if (kk == 0 && s + h + 1 < nst) {
+                        // stage s + h + 1 (register set (h + 1) & 1) into the other buffer, behind the first MFMAs
+                        store_stage<T, LA, TMR, NT>(As + (h ^ 1) * KT * LDA, ra[h ^ 1], tid);
+                        store_stage<T, LB, TNC, NT>(Bs + (h ^ 1) * KT * LDB, rb[h ^ 1], tid);
+                        if (s + h + 3 < nst) {
+                            load_stage<T, LA, TMR, NT>(A0, ldA, (s + h + 3) * KT, ra[h ^ 1], tid);
+                            load_stage<T, LB, TNC, NT>(B0, ldB, (s + h + 3) * KT, rb[h ^ 1], tid);
+                        }
+                    }
                 }
+                __syncthreads();
             }
         }
     }
@@ -1087,28 +1114,94 @@ __device__ __forceinline__ void syrk_rect_body(const GemmArgs& g, const int lin,
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int e = 0; e < 4; ++e)
-                Ct[(size_t)(wm0 + i * 16 + Mfma<T>::row(lane, e)) * g.ldC + wn0 + j * 16 + (lane & 15)] = acc[i][j][e];
+                Ct[(size_t)(wm0 + i * 16 + Mfma<T>::row(lane, e)) * ldC + wn0 + j * 16 + (lane & 15)] = acc[i][j][e];
 }
 
+// One block of a filler set: block b of the launch's filler range -> (job, component, tile) -> operands (fill_sched.h).
 template <typename T>
-__global__ __launch_bounds__(256, 2) void syrk_rect_kernel(GemmArgs g) {
-    __shared__ __align__(16) unsigned char lds[2 * KT * (128 + 16 + 64 + 16) * sizeof(T)];
-    syrk_rect_body<T>(g, blockIdx.x, lds);
+__device__ __forceinline__ void fill_dispatch(const FillSet& fs, int b, unsigned char* lds) {
+    int ji = 0;
+    while (ji + 1 < fs.njobs && b >= fs.job[ji].nblk) { b -= fs.job[ji].nblk; ++ji; }
+    const FillJob jb = fs.job[ji];
+    const int ld = fs.npad;
+    if (jb.type == lcgp_fill::FILL_TRI_T || jb.type == lcgp_fill::FILL_TRI_W) {
+        GemmArgs g;
+        g.sA = g.sB = g.sC = fs.mat; g.ldA = g.ldB = g.ldC = ld; g.nb = fs.nb;
+        g.p0 = jb.R0; g.p1 = jb.R1; g.p2 = jb.j0; g.p3 = 0; g.q = fs.q; g.t0 = 0; g.skipq = 1;
+        if (jb.type == lcgp_fill::FILL_TRI_T) {
+            g.A = fs.M; g.B = fs.W; g.C = fs.V;
+            gemm_body<T, OP_TRTRI_T, 64, 4>(g, b + jb.t0 * fs.q, lds);       // (a job may be split over launches)
+        } else {
+            g.A = fs.W; g.B = fs.V; g.C = fs.W;
+            gemm_body<T, OP_TRTRI_W, 64, 4>(g, b + jb.t0 * fs.q, lds);
+        }
+        return;
+    }
+    const int k = b % fs.q;
+    int t = b / fs.q + jb.t0;
+    T* M = (T*)fs.M + (size_t)k * fs.mat;
+    T* W = (T*)fs.W + (size_t)k * fs.mat;
+    T* V = (T*)fs.V + (size_t)k * fs.mat;
+    const int kb0 = jb.kb0, kb1 = jb.kb1;
+    if (jb.type == lcgp_fill::FILL_SYRK) {
+        // M[R, j] -= sum_k M[R, k] M[j, k]^T over the block columns [kb0, kb1)
+        int j = jb.j0;
+        while (t >= jb.R1 - (j >> 1)) { t -= jb.R1 - (j >> 1); ++j; }
+        const int R = (j >> 1) + t;
+        rect_tile<T, MK, MK, true>(M + (size_t)R * 128 * ld + (size_t)kb0 * TS, ld, M + (size_t)j * TS * ld + (size_t)kb0 * TS, ld,
+                                   M + (size_t)R * 128 * ld + (size_t)j * TS, ld, (kb1 - kb0) * (TS / KT), false, lds);
+    } else if (jb.type == lcgp_fill::FILL_BROW) {
+        // W[R, j] = -W[R, kb0 .. ] V[kb0 .., j]: row block R of the panel's block inverse (lower triangular: k < 2R + 2)
+        const int nc = jb.j1 - jb.j0;
+        const int R = jb.R0 + t / nc, j = jb.j0 + t % nc;
+        const int ke = kb1 < 2 * R + 2 ? kb1 : 2 * R + 2;
+        rect_tile<T, MK, KM, true>(W + (size_t)R * 128 * ld + (size_t)kb0 * TS, ld, V + (size_t)kb0 * TS * ld + (size_t)j * TS, ld,
+                                   W + (size_t)R * 128 * ld + (size_t)j * TS, ld, (ke - kb0) * (TS / KT), true, lds);
+    } else if (jb.type == lcgp_fill::FILL_CUPD) {
+        // V[R, j] (+)= M[R, kb0 ..] W[kb0 .., j]; a column inside the panel starts at its own 128-aligned block row (zeros
+        // above) and is the first contribution to the tile
+        const int nc = jb.j1 - jb.j0;
+        const int R = jb.R0 + t / nc, j = jb.j0 + t % nc;
+        const bool own = j >= kb0;
+        const int ks = kb0 + (own ? ((j - kb0) & ~1) : 0);
+        rect_tile<T, MK, KM, false>(M + (size_t)R * 128 * ld + (size_t)ks * TS, ld, W + (size_t)ks * TS * ld + (size_t)j * TS, ld,
+                                    V + (size_t)R * 128 * ld + (size_t)j * TS, ld, (kb1 - ks) * (TS / KT), own, lds);
+    } else {
+        // FILL_DUPD: V[R, j] (+)= W[kb0 .., R]^T W[kb0 .., j]; a row block inside (or below) the K range starts at its own
+        // block row and is written for the first time
+        int R = (int)((sqrt(4.0 * (double)t + 1.0) - 1.0) * 0.5);
+        while ((R + 1) * (R + 2) <= t) ++R;
+        while (R * (R + 1) > t) --R;
+        const int j = t - R * (R + 1);
+        const bool own = 2 * R >= kb0;
+        const int ks = own ? 2 * R : kb0;
+        rect_tile<T, KM, KM, false>(W + (size_t)ks * TS * ld + (size_t)R * 128, ld, W + (size_t)ks * TS * ld + (size_t)j * TS, ld,
+                                    V + (size_t)R * 128 * ld + (size_t)j * TS, ld, (kb1 - ks) * (TS / KT), own, lds);
+    }
+}
+
+constexpr int FILL_LDS_BYTES = 2 * KT * (128 + 16 + 64 + 16) * 8;
+
+// filler jobs on their own (what the chain launches could not carry, and the tail of the progressive inverse)
+template <typename T>
+__global__ __launch_bounds__(256, 2) void fill_kernel(FillSet fs) {
+    __shared__ __align__(16) unsigned char lds[FILL_LDS_BYTES];
+    fill_dispatch<T>(fs, blockIdx.x, lds);
 }
 
 // Heterogeneous launches.  The panel chain of the Cholesky (diagonal block -> panel TRMM -> panel update, 64 times)
 // is a sequence of small dependent launches that leave most CUs idle, and two HIP streams cannot overlap them with
 // the wide trailing update on this platform.  So the chain launches CARRY independent work: blocks
-// beyond the chain's own are "filler" tiles of the previous panel's trailing update (128x64 tiles, K = panel width),
-// which touch columns the chain of the current panel neither reads nor writes.  No inter-workgroup dependency
+// beyond the chain's own are filler tiles (fill_sched.h): the previous panel's trailing update on columns the chain of
+// the current panel neither reads nor writes, and the jobs of the progressive inverse.  No inter-workgroup dependency
 // exists inside such a launch; stream order between launches provides all the ordering.
 template <typename T>
 __global__ __launch_bounds__(256, 2) void leaf_fill_kernel(T* __restrict__ M, T* __restrict__ W, size_t mat, int npad, int jb,
                                                         double* __restrict__ logdet, int* __restrict__ info,
-                                                        int q, GemmArgs f) {
+                                                        int q, FillSet fs) {
     __shared__ __align__(16) unsigned char lds[LEAF_LDS_BYTES];
     if ((int)blockIdx.x < q) leaf_body<T>(lds, blockIdx.x, M, W, mat, npad, jb, logdet, info);
-    else syrk_rect_body<T>(f, blockIdx.x - q, lds);
+    else fill_dispatch<T>(fs, blockIdx.x - q, lds);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -1137,8 +1230,7 @@ struct StepArgs {
     int n_trmm;          // TRMM tiles per component INCLUDING the special one: rows c+1 .. nb-1
     int n_upd;           // delayed-update tiles per component
     double* logdet; int* info;
-    int nfill;           // filler blocks
-    GemmArgs f;          // filler
+    FillSet fs;          // filler jobs (fs.nblk blocks)
 };
 
 template <typename T>
@@ -1293,9 +1385,9 @@ __global__ __launch_bounds__(256, 2) void chain_step_kernel(StepArgs a) {
     const int nspecial = a.has_special * a.q;
     int t = -1, k = 0;
     if (b < nspecial) { t = 0; k = b; }
-    else if (b < nspecial + a.nfill) { syrk_rect_body<T>(a.f, b - nspecial, lds); return; }
+    else if (b < nspecial + a.fs.nblk) { fill_dispatch<T>(a.fs, b - nspecial, lds); return; }
     else {
-        b -= nspecial + a.nfill;
+        b -= nspecial + a.fs.nblk;
         if (b < (a.n_trmm - a.has_special) * a.q) { k = b % a.q; t = b / a.q + a.has_special; }
         else b -= (a.n_trmm - a.has_special) * a.q;
     }
@@ -1776,107 +1868,42 @@ inline lcgp_sched default_sched() {
     s.fill_leaf = 248;             // filler blocks (128x64 tiles) carried by a diagonal-block launch
     s.fill_step = 248;             // ... and by a chain-step launch that ends in a diagonal block
     s.leaf_in_wide = 1024;         // a trailing update of at most this many 64x64 tiles also factors the next diagonal block
+    s.progressive_tiles = 600;     // L^-1 and A^-1 formed behind the chain up to this many 128x128 lower tiles x components
+                                   // (n = 4096: one component per rank; measured 2.72 -> 2.55 ms there, slower from two on)
+    s.progressive_far = 1;         // ... with the far columns of the trailing updates still riding on the chain
     return s;
 }
 
 inline int check_sched(const lcgp_sched& s) {
     if (s.outer_blocks < 0 || s.outer_blocks > 64) return bad("sched.outer_blocks must be in [0, 64]");
     if (s.syrk_small_tiles < 0 || s.trtri_small_tiles < 0 || s.lauum_small_tiles < 0 || s.trtri_level_small < 0 ||
-        s.fill_leaf < 0 || s.fill_step < 0 || s.leaf_in_wide < 0)
+        s.fill_leaf < 0 || s.fill_step < 0 || s.leaf_in_wide < 0 || s.progressive_tiles < 0)
         return bad("sched fields must be >= 0");
     return 0;
 }
 
-// 128 x 64 filler tiles over the 64-columns [c_lo, c_hi): column c has nb/2 - c/2 row blocks
-inline long rect_tiles(int nb, int c_lo, int c_hi) {
-    long n = 0;
-    for (int c = c_lo; c < c_hi; ++c) n += nb / 2 - (c >> 1);
-    return n;
-}
+using lcgp_fill::trapezoid_tiles;
 
-inline int trapezoid_tiles(int nb, int c_lo, int c_hi) {
-    return (c_hi - c_lo) * nb - (c_lo + c_hi - 1) * (c_hi - c_lo) / 2;
-}
-
-// Filler work carried by the chain launches: a range of 128x64 tiles of a trailing update (see leaf_fill_kernel).
-struct Filler {
-    GemmArgs f;          // f.q set
-    long next = 0;       // next tile (enumeration over the columns [f.p2, f.nb))
-    long total = 0;
-    bool active() const { return next < total; }
-    // reserves up to `cap_blocks` blocks (= tiles x components); returns the block count and fills `out`
-    int take(int cap_blocks, GemmArgs& out) {
-        if (!active() || cap_blocks < f.q) return 0;
-        long n = cap_blocks / f.q;
-        if (n > total - next) n = total - next;
-        out = f;
-        out.t0 = (int)next;
-        next += n;
-        return (int)n * f.q;
-    }
-};
-
-// One outer panel [J, pe) of the Cholesky: the diagonal block J on its own (unless the previous trailing-update
-// launch factored it), then ONE launch per 64-column step (chain_step_kernel); every launch may carry filler tiles.
+// launches the filler set on its own
 template <typename T>
-int potrf_panel(hipStream_t st, const Ws& w, const lcgp_sched& sc, int J, int pe, Filler* fill, bool leaf_done,
-                bool next_leaf_in_wide) {
-    T* M = (T*)(w.base + w.off_M);
-    T* W = (T*)(w.base + w.off_W);
-    double* logdet = (double*)(w.base + w.off_logdet);
-    int* info = (int*)(w.base + w.off_info);
-    GemmArgs fa;
-    int nf = 0;
-    if (!leaf_done) {
-        nf = fill ? fill->take(sc.fill_leaf, fa) : 0;
-        if (nf > 0) {
-            hipLaunchKernelGGL((leaf_fill_kernel<T>), dim3(w.q + nf), dim3(256), 0, st, M, W, w.mat, w.npad, J, logdet, info,
-                               w.q, fa);
-        } else {
-            hipLaunchKernelGGL((leaf_kernel<T>), dim3(w.q), dim3(256), 0, st, M, W, w.mat, w.npad, J, logdet, info);
-        }
-        CHECK_LAUNCH("leaf_kernel");
-    }
-    for (int c = J; c < pe && c + 1 < w.nb; ++c) {
-        StepArgs a;
-        a.M = M; a.W = W; a.mat = w.mat; a.npad = w.npad; a.nb = w.nb;
-        a.c = c; a.J = J; a.pe = pe; a.q = w.q;
-        a.diag_end = pe + (next_leaf_in_wide ? 1 : 0);
-        a.has_special = c + 1 < pe ? 1 : 0;
-        a.n_trmm = w.nb - 1 - c;
-        a.n_upd = 0;
-        if (c > J && c + 1 < pe) a.n_upd = w.nb - (c + 1) - 1;     // the tiles below the diagonal of column c + 1
-        a.logdet = logdet; a.info = info;
-        nf = (fill && a.has_special) ? fill->take(sc.fill_step, fa) : 0;
-        a.f = fa; a.nfill = nf;
-        const long nblk = (long)(a.n_trmm + a.n_upd) * w.q + nf;
-        hipLaunchKernelGGL((chain_step_kernel<T>), dim3((unsigned)nblk), dim3(256), 0, st, a);
-        CHECK_LAUNCH("chain_step_kernel");
-    }
-    // whatever the chain could not carry runs as one plain launch
-    if (fill && fill->active()) {
-        GemmArgs rest = fill->f;
-        rest.t0 = (int)fill->next;
-        const long n = fill->total - fill->next;
-        fill->next = fill->total;
-        hipLaunchKernelGGL((syrk_rect_kernel<T>), dim3((unsigned)(n * w.q)), dim3(256), 0, st, rest);
-        CHECK_LAUNCH("syrk_rect_kernel");
-    }
+int launch_fill(hipStream_t st, const FillSet& fs) {
+    if (fs.nblk <= 0) return 0;
+    hipLaunchKernelGGL((fill_kernel<T>), dim3((unsigned)fs.nblk), dim3(256), 0, st, fs);
+    CHECK_LAUNCH("fill_kernel");
     return 0;
 }
 
 // trailing update with the panel [J, pe) of the tile columns [c_lo, c_hi) (64-block units, all rows below)
 template <typename T>
-int potrf_trailing(hipStream_t st, const Ws& w, const lcgp_sched& sc, int J, int pe, int c_lo, int c_hi, bool tiles128,
-                   bool with_leaf) {
+int potrf_trailing(hipStream_t st, const Ws& w, int J, int pe, int c_lo, int c_hi, bool tiles128, bool with_leaf) {
     if (c_lo >= c_hi) return 0;
     T* M = (T*)(w.base + w.off_M);
     GemmArgs g;
     g.sA = g.sB = g.sC = w.mat; g.ldA = g.ldB = g.ldC = w.npad;
     g.A = M; g.B = M; g.C = M;
-    // 128x128 tiles when the panel boundaries are 128-aligned AND the launch has enough of them to fill the chip;
-    // a launch with few tiles is bounded by the duration of one tile, which is 4x shorter on 64x64 tiles
-    if (tiles128 && (long long)w.q * trapezoid_tiles(w.nb / 2, c_lo / 2, c_hi / 2) >= sc.syrk_small_tiles) {
+    // 128x128 tiles when the panel boundaries are 128-aligned AND the launch has enough of them to fill the chip (the
+    // plan decides); a launch with few tiles is bounded by the duration of one tile, which is 4x shorter on 64x64 tiles
+    if (tiles128) {
         g.nb = w.nb / 2; g.p0 = J / 2; g.p1 = pe / 2; g.p2 = c_lo / 2; g.p3 = c_hi / 2;
         const int nt = trapezoid_tiles(w.nb / 2, c_lo / 2, c_hi / 2);
         if (with_leaf) {
@@ -1904,76 +1931,77 @@ int potrf_trailing(hipStream_t st, const Ws& w, const lcgp_sched& sc, int J, int
     return launch_gemm<T, OP_SYRK>(st, g, nt, w.q);
 }
 
+// progressive inverse behind the chain (fill_sched.h): worth it when the chain launches have room for its jobs, i.e. with
+// few components per rank (sched.progressive_tiles: at most this many 128x128 lower tiles x components; needs a panel
+// width that is a power of two so that the levels of the block inverse stay inside a panel)
+inline bool use_progressive(const Ws& w, const lcgp_sched& sc, int ob) {
+    if (sc.progressive_tiles <= 0 || ob < 2 || (ob & (ob - 1)) != 0) return false;
+    const int nb2 = w.nb / 2;
+    return (long long)w.q * (nb2 * (nb2 + 1) / 2) <= sc.progressive_tiles;
+}
+
 // Two-level right-looking Cholesky.  Outer panels of `ob` 64-blocks: inside a panel every 64-column step is ONE launch
 // (chain_step_kernel) that only touches the panel's block column and the rest of the panel; the trailing matrix is read
 // and written once per outer panel with K = 64 ob.  The trailing update of panel J is split by columns into one wide
 // launch (the columns of panel J+1 and as many more as do not fit below) and its right-most columns, which the chain
 // launches of panel J+1 carry as filler tiles -- the chain leaves >= 97 % of the CUs idle, and a second HIP stream
-// cannot fill them on this platform.
+// cannot fill them on this platform.  The launch sequence is PLANNED first (fill_sched.h: Planner, host
+// only, also replayed on the CPU by tests/native/test_fill_sched.cpp) and then enqueued here launch by launch.
 template <typename T>
-int do_potrf(hipStream_t st, const Ws& w, const lcgp_sched& sc, bool stats_zeroed = false) {
+int do_potrf(hipStream_t st, const Ws& w, const lcgp_sched& sc, bool stats_zeroed = false, bool with_inverse = false,
+             bool* inverse_done = nullptr) {
+    T* M = (T*)(w.base + w.off_M);
+    T* W = (T*)(w.base + w.off_W);
     double* logdet = (double*)(w.base + w.off_logdet);
     int* info = (int*)(w.base + w.off_info);
     if (!stats_zeroed) {       // (the NLL path's kernel-build launch has done it)
         hipLaunchKernelGGL(zero_stats_kernel, dim3((w.q + 63) / 64), dim3(64), 0, st, logdet, info, w.q);
         CHECK_LAUNCH("zero_stats");
     }
-    const int ob = sc.outer_blocks < 1 ? (sizeof(T) == 4 ? 8 : 4) : sc.outer_blocks;
-    const bool t128 = (ob & 1) == 0;
-    Filler fill;
-    bool leaf_done = false;
-    // filler capacity of a panel's chain launches, with and without a diagonal-block launch of its own
-    const int cap_with_leaf = sc.fill_leaf + (ob - 1) * sc.fill_step;
-    const int cap_no_leaf = (ob - 1) * sc.fill_step;
-    for (int J = 0; J < w.nb; J += ob) {
-        const int pe = J + ob < w.nb ? J + ob : w.nb;
-        const int mid = pe + ob < w.nb ? pe + ob : w.nb;     // the next panel's own columns are never filler
-        auto first_filler_column = [&](int cap_blocks) {
-            int c = w.nb;
-            // filler rides on the chain launches of the NEXT panel [pe, mid): it must stay clear of that panel's
-            // columns and, when those chain steps pre-apply the panel to the diagonal block (mid, mid) for a
-            // trailing-update launch that factors it, of column `mid` too
-            const int lo = mid + (sc.leaf_in_wide ? 2 : 0);
-            if (t128 && cap_blocks >= w.q && lo < w.nb) {
-                const long cap_tiles = cap_blocks / w.q;
-                while (c - 2 >= lo && rect_tiles(w.nb, c - 2, w.nb) <= cap_tiles) c -= 2;
+    lcgp_fill::PlanParams pp;
+    pp.nb = w.nb; pp.q = w.q;
+    pp.ob = sc.outer_blocks < 1 ? (sizeof(T) == 4 ? 8 : 4) : sc.outer_blocks;
+    pp.syrk_small_tiles = sc.syrk_small_tiles; pp.fill_leaf = sc.fill_leaf; pp.fill_step = sc.fill_step;
+    pp.leaf_in_wide = sc.leaf_in_wide;
+    pp.progressive = with_inverse && use_progressive(w, sc, pp.ob);
+    pp.far_rides = !(pp.progressive && sc.progressive_far == 0);
+    if (inverse_done) *inverse_done = pp.progressive;
+    lcgp_fill::Planner plan(pp);
+    plan.run();
+    if (plan.failed) return bad("internal: the filler queue did not drain");
+    for (lcgp_fill::Launch& l : plan.launches) {
+        FillSet& fs = l.fs;
+        fs.M = w.base + w.off_M; fs.W = w.base + w.off_W; fs.V = w.base + w.off_V;
+        fs.mat = w.mat; fs.npad = w.npad; fs.nb = w.nb; fs.q = w.q;
+        int rc = 0;
+        switch (l.kind) {
+            case lcgp_fill::L_LEAF:
+                if (fs.nblk > 0)
+                    hipLaunchKernelGGL((leaf_fill_kernel<T>), dim3(w.q + fs.nblk), dim3(256), 0, st, M, W, w.mat, w.npad, l.J,
+                                       logdet, info, w.q, fs);
+                else
+                    hipLaunchKernelGGL((leaf_kernel<T>), dim3(w.q), dim3(256), 0, st, M, W, w.mat, w.npad, l.J, logdet, info);
+                CHECK_LAUNCH("leaf_kernel");
+                break;
+            case lcgp_fill::L_STEP: {
+                StepArgs a;
+                a.M = M; a.W = W; a.mat = w.mat; a.npad = w.npad; a.nb = w.nb;
+                a.c = l.c; a.J = l.J; a.pe = l.pe; a.q = w.q;
+                a.diag_end = l.diag_end; a.has_special = l.has_special; a.n_trmm = l.n_trmm; a.n_upd = l.n_upd;
+                a.logdet = logdet; a.info = info;
+                a.fs = fs;
+                const long nblk = (long)(a.n_trmm + a.n_upd) * w.q + fs.nblk;
+                hipLaunchKernelGGL((chain_step_kernel<T>), dim3((unsigned)nblk), dim3(256), 0, st, a);
+                CHECK_LAUNCH("chain_step_kernel");
+                break;
             }
-            return c;
-        };
-        auto wide_on_small_tiles = [&](int c_hi) {
-            return !(t128 && (long long)w.q * trapezoid_tiles(w.nb / 2, pe / 2, c_hi / 2) >= sc.syrk_small_tiles);
-        };
-        // decided BEFORE the panel's chain, which then pre-applies the panel to the next diagonal block:
-        // when the update runs on 64x64 tiles (few tiles: late panels, few components) it also factors the next
-        // panel's first diagonal block (wide_leaf_kernel).  With many 128x128 tiles that does not pay: the
-        // diagonal-block launch carries filler of its own and the 8-wave tile kernel is the faster one.
-        int cf = w.nb;                                         // first filler column
-        bool next_leaf = false;
-        if (pe < w.nb) {
-            cf = first_filler_column(cap_with_leaf);
-            if (sc.leaf_in_wide && wide_on_small_tiles(cf)) {
-                const int cf3 = first_filler_column(cap_no_leaf);
-                // (that kernel holds two workgroups per CU, the plain 64-tile kernel four: launches of few rounds)
-                if (wide_on_small_tiles(cf3) && (long long)w.q * trapezoid_tiles(w.nb, pe, cf3) <= sc.leaf_in_wide) {
-                    next_leaf = true;
-                    cf = cf3;
-                }
-            }
+            case lcgp_fill::L_TRAIL:
+                rc = potrf_trailing<T>(st, w, l.J, l.pe, l.c_lo, l.c_hi, l.tiles128 != 0, l.with_leaf != 0);
+                break;
+            default:
+                rc = launch_fill<T>(st, fs);
         }
-        int rc = potrf_panel<T>(st, w, sc, J, pe, fill.active() ? &fill : nullptr, leaf_done, next_leaf);
         if (rc) return rc;
-        if (pe >= w.nb) break;
-        rc = potrf_trailing<T>(st, w, sc, J, pe, pe, cf, t128, next_leaf);   // one wide launch
-        if (rc) return rc;
-        leaf_done = next_leaf;
-        fill = Filler();
-        if (cf < w.nb) {
-            GemmArgs& f = fill.f;
-            f.A = w.base + w.off_M; f.B = f.A; f.C = (void*)f.A;
-            f.sA = f.sB = f.sC = w.mat; f.ldA = f.ldB = f.ldC = w.npad; f.nb = w.nb;
-            f.p0 = J; f.p1 = pe; f.p2 = cf; f.p3 = w.nb; f.q = w.q; f.t0 = 0; f.skipq = 0;
-            fill.total = rect_tiles(w.nb, cf, w.nb);
-        }
     }
     return 0;
 }
@@ -2064,11 +2092,14 @@ int do_nll_grad(hipStream_t st, const Ws& w, const lcgp_sched& sc, const void* x
     if (rc) return rc;
     T* b = (T*)(w.base + w.off_b);
     T* z = (T*)(w.base + w.off_z);
-    rc = do_potrf<T>(st, w, sc, true);
+    bool inverse_done = false;     // the progressive inverse has left L^-1 and A^-1 behind the factorisation
+    rc = do_potrf<T>(st, w, sc, true, true, &inverse_done);
     if (rc) return rc;
     bool z_partials = false;       // z = A^-1 b: per-tile partials from the 128-tile LAUUM's epilogue, or a pass of its own
-    rc = do_potri<T>(st, w, sc, &z_partials);
-    if (rc) return rc;
+    if (!inverse_done) {
+        rc = do_potri<T>(st, w, sc, &z_partials);
+        if (rc) return rc;
+    }
     if (z_partials) {
         const int nb2 = w.nb / 2;
         hipLaunchKernelGGL((symv_reduce_kernel<T, 128>), dim3(nb2, w.q), dim3(256), 0, st,

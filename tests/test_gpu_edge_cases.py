@@ -164,7 +164,12 @@ def test_schedule_parameters_do_not_change_results():
                        dict(fill_leaf=0, fill_step=0), dict(fill_leaf=16, fill_step=24), dict(leaf_in_wide=0),
                        dict(leaf_in_wide=100000), dict(leaf_in_wide=100000, outer_blocks=2), dict(trtri_level_small=0),
                        dict(trtri_level_small=100000, trtri_small_tiles=0), dict(lauum_small_tiles=0),
-                       dict(lauum_small_tiles=100000, trtri_small_tiles=100000)):
+                       dict(lauum_small_tiles=100000, trtri_small_tiles=100000),
+                       # the inverse formed behind the chain (fill_sched.h) and after it
+                       dict(progressive_tiles=0), dict(progressive_tiles=1 << 30), dict(progressive_tiles=1 << 30, outer_blocks=2),
+                       dict(progressive_tiles=1 << 30, outer_blocks=8), dict(progressive_tiles=1 << 30, fill_leaf=0, fill_step=0),
+                       dict(progressive_tiles=1 << 30, fill_leaf=12, fill_step=20), dict(progressive_tiles=1 << 30, progressive_far=0),
+                       dict(progressive_tiles=1 << 30, leaf_in_wide=0), dict(progressive_tiles=1 << 30, outer_blocks=3)):
             eng.sched = _sched(**fields)
             v, g = m.loss_and_grad(u)
             assert abs(v - ref_v) <= 1e-11 * abs(ref_v), fields
@@ -186,7 +191,10 @@ def test_wide_tile_schedules_agree_at_medium_size():
         for fields in (dict(syrk_small_tiles=16), dict(syrk_small_tiles=16, leaf_in_wide=0),
                        dict(syrk_small_tiles=16, leaf_in_wide=100000), dict(syrk_small_tiles=16, fill_leaf=40, fill_step=56),
                        dict(syrk_small_tiles=16, outer_blocks=2), dict(syrk_small_tiles=16, outer_blocks=8),
-                       dict(syrk_small_tiles=200, leaf_in_wide=300), dict(syrk_small_tiles=1, fill_leaf=8, fill_step=8)):
+                       dict(syrk_small_tiles=200, leaf_in_wide=300), dict(syrk_small_tiles=1, fill_leaf=8, fill_step=8),
+                       dict(progressive_tiles=0), dict(progressive_tiles=1 << 30), dict(progressive_tiles=1 << 30, syrk_small_tiles=16),
+                       dict(progressive_tiles=1 << 30, progressive_far=0, syrk_small_tiles=16),
+                       dict(progressive_tiles=1 << 30, fill_leaf=40, fill_step=56), dict(progressive_tiles=1 << 30, outer_blocks=8)):
             eng.sched = _sched(**fields)
             v, g = m.loss_and_grad(u)
             assert abs(v - ref_v) <= 1e-11 * abs(ref_v), fields
@@ -208,6 +216,35 @@ def test_chain_variants_match_oracle_at_several_sizes():
             _same(m, o, u)
 
 
+def test_progressive_inverse_with_jobs_split_over_launches():
+    """The inverse formed behind the factorisation (fill_sched.h) where the filler capacity cuts jobs at every kind of
+    boundary: n = 2048 with 6 components splits a level of a block inverse over two launches (the shape that exposed a
+    job-offset bug during development), tiny capacities split every job many times.  L^-1, A^-1, z, NLL and gradient
+    against the schedule that inverts after the factorisation; predictions (which read L^-1) as well."""
+    x, y = synth.make_full(351, 2048, 3, 12, 6)
+    m = LCGP(y=y, x=x, q=6)
+    u = synth.param_points(351, m._get_flat())[1]
+    eng = m._get_engine()
+    try:
+        eng.sched = _sched(progressive_tiles=0)
+        ref_v, ref_g = m.loss_and_grad(u)
+        ref_p = [t.numpy() for t in m.predict(x[:50] + 0.003)]
+        ref_w, ref_a, ref_z = np.tril(eng.fetch_matrix(1, 5)), np.tril(eng.fetch_matrix(2, 5)), eng.fetch_vector(1, 5)
+        for fields in (dict(progressive_tiles=1 << 30), dict(progressive_tiles=1 << 30, fill_leaf=30, fill_step=18),
+                       dict(progressive_tiles=1 << 30, fill_leaf=6, fill_step=6), dict(progressive_tiles=1 << 30, progressive_far=0)):
+            eng.sched = _sched(**fields)
+            v, g = m.loss_and_grad(u)
+            assert abs(v - ref_v) <= 1e-11 * abs(ref_v), fields
+            assert np.max(np.abs(g - ref_g)) <= 1e-10 * np.max(np.abs(ref_g)), fields
+            assert np.max(np.abs(np.tril(eng.fetch_matrix(1, 5)) - ref_w)) <= 1e-11 * np.max(np.abs(ref_w)), fields
+            assert np.max(np.abs(np.tril(eng.fetch_matrix(2, 5)) - ref_a)) <= 1e-10 * np.max(np.abs(ref_a)), fields
+            assert np.max(np.abs(eng.fetch_vector(1, 5) - ref_z)) <= 1e-10 * np.max(np.abs(ref_z)), fields
+            for a, b in zip(ref_p, (t.numpy() for t in m.predict(x[:50] + 0.003))):
+                assert np.max(np.abs(a - b)) <= 1e-10 * np.max(np.abs(a)), fields
+    finally:
+        eng.sched = None
+
+
 def _first_bad_pivot(a):
     """1-based index of the first non-positive pivot of an unblocked Cholesky of `a` (LAPACK's info), 0 if none."""
     a = a.copy()
@@ -220,7 +257,8 @@ def _first_bad_pivot(a):
     return 0
 
 
-@pytest.mark.parametrize('variant', [{}, dict(leaf_in_wide=0), dict(outer_blocks=2), dict(fill_leaf=0, fill_step=0)])
+@pytest.mark.parametrize('variant', [{}, dict(leaf_in_wide=0), dict(outer_blocks=2), dict(fill_leaf=0, fill_step=0),
+                                     dict(progressive_tiles=0), dict(progressive_tiles=1 << 30)])
 def test_info_is_the_first_bad_pivot(variant):
     """info of the output block = position of the first non-positive pivot (as LAPACK dpotrf reports it), wherever
     it falls: first block, inside a later 16-column panel of a diagonal block, in a later block or panel."""
@@ -253,8 +291,10 @@ def test_random_shapes_and_schedules_against_oracle():
     variants = [{}, dict(leaf_in_wide=0), dict(leaf_in_wide=100000), dict(outer_blocks=2), dict(outer_blocks=3),
                 dict(outer_blocks=8), dict(fill_leaf=8, fill_step=16), dict(syrk_small_tiles=1),
                 dict(syrk_small_tiles=1, leaf_in_wide=100000), dict(syrk_small_tiles=1, fill_leaf=24, fill_step=40),
-                dict(trtri_small_tiles=0, trtri_level_small=0, lauum_small_tiles=0)]
-    for case in range(14):
+                dict(trtri_small_tiles=0, trtri_level_small=0, lauum_small_tiles=0),
+                dict(progressive_tiles=0), dict(progressive_tiles=1 << 30, fill_leaf=16, fill_step=8),
+                dict(progressive_tiles=1 << 30, outer_blocks=2), dict(progressive_tiles=1 << 30, progressive_far=0)]
+    for case in range(18):
         n = int(rng.integers(1, 3)) if case == 0 else int(rng.integers(2, 1100))
         d = int(rng.integers(1, 5))
         p = int(rng.integers(1, 7))
