@@ -38,6 +38,9 @@ def parse():
     ap.add_argument('--q', type=int, default=None, help='override q (debug only: e.g. one rank\'s share of the components)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-stages', action='store_true')
+    ap.add_argument('--no-fit', action='store_true', help='skip the wall-clock fit() leg')
+    ap.add_argument('--blocks', type=int, default=3, help='timed blocks of --steps evaluations (the first one is `value`)')
+    ap.add_argument('--cpu-repeats', type=int, default=5)
     ap.add_argument('--predict', type=int, default=2000, help='new inputs of the predict leg (K6); 0 = skip')
     ap.add_argument('--backend', default='nccl', help='process-group backend for --gpus > 1 (nccl = RCCL)')
     return ap.parse_args()
@@ -119,7 +122,7 @@ def host_cores():
     return cores
 
 
-def cpu_baseline(m, budget_s=12.0, repeats=3):
+def cpu_baseline(m, budget_s=12.0, repeats=5):
     """Reference algorithm (eigh form + autodiff) and Cholesky form for ONE component of the same workload on the
     host cores: median of `repeats` samples each, after one warm-up probe.  Bounded: the probe at n=1024 picks the
     largest prefix of the training set (n, n/2, n/4 ...) whose predicted eigh-form time fits `budget_s` per sample; a
@@ -186,7 +189,11 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs a GPU (the hot path has no CPU fallback)')
     ndev = torch.cuda.device_count()
-    dev_index = local_rank % ndev          # (more ranks than devices only happens in single-GPU rehearsals)
+    if world > ndev and args.backend == 'nccl':
+        # one rank per GPU or nothing: RCCL ranks folded onto one device would time something else than --gpus N
+        raise SystemExit('bench.py --gpus %d: only %d GPU(s) visible; the nccl (RCCL) backend needs one device per rank '
+                         '(a single-GPU rehearsal of the launch line is `--backend gloo`)' % (world, ndev))
+    dev_index = local_rank % ndev          # (more ranks than devices: gloo rehearsals on one GPU only, see above)
     torch.cuda.set_device(dev_index)
     import torch.distributed as dist
     if world > 1:
@@ -215,18 +222,27 @@ def main():
     last = None
     for i in range(args.warmup):
         last = m.loss_and_grad(pts[i % len(pts)])
-    barrier()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        last = m.loss_and_grad(pts[i % len(pts)])
-    barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device='cuda' if args.backend == 'nccl' else 'cpu')
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
 
-    log('timed %d steps: %.3f ms/step' % (args.steps, 1e3 * dt / args.steps))
+    def timed_block():
+        """EXACTLY --steps evaluations between two barrier + synchronize brackets; (local seconds, max over ranks)."""
+        barrier()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            m.loss_and_grad(pts[i % len(pts)])
+        barrier()
+        dt_local = time.perf_counter() - t0
+        dt_max = dt_local
+        if world > 1:
+            tt = torch.tensor([dt_local], dtype=torch.float64, device='cuda' if args.backend == 'nccl' else 'cpu')
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt_max = float(tt.item())
+        return dt_local, dt_max
+
+    # block 0 is the contract's measurement (`value`, `ms_per_step`); the further blocks only show the spread
+    blocks = [timed_block() for _ in range(max(1, args.blocks))]
+    dt_local, dt = blocks[0]
+    per_block_ms = [1e3 * b[1] / args.steps for b in blocks]
+    log('timed %d block(s) of %d steps: %s ms/step' % (len(blocks), args.steps, ['%.3f' % v for v in per_block_ms]))
     n, d, p, q = int(m.n), int(m.d), int(m.p), int(m.q)
     flops_eval = float(q) * float(n) ** 3                       # potrf n^3/3 + inverse 2n^3/3 per component
     peak = FP64_MFMA_PEAK_TFLOPS if dtype == 'float64' else FP32_MFMA_PEAK_TFLOPS
@@ -237,15 +253,91 @@ def main():
                            % (args.config - 1, n, d, p, q, cfg['submethod']),
                            n=n, d=d, p=p, q=q, parallelism='latent components k -> rank k mod %d' % world,
                            q_local_rank0=len(m._local_ks)))
+    out['ms_per_step_blocks'] = dict(values=per_block_ms, median=float(np.median(per_block_ms)), min=float(np.min(per_block_ms)),
+                                     max=float(np.max(per_block_ms)),
+                                     note='block 0 is `value`/`ms_per_step`; every block = --steps evaluations, max over ranks')
     out['path_tflops'] = flops_eval / (dt / args.steps) / 1e12
     out['path_frac_of_mfma_peak'] = out['path_tflops'] / (peak * world)
+    out['library'] = dict(source_hash=_hip.loaded_hash(), version=int(_hip.load().lcgp_version()))
 
+    # ---- per-rank stage timings (every rank that holds components times its own kernels with HIP events) ----
+    ql = len(m._local_ks)
+    mine = dict(rank=rank, local_rank=local_rank, device_index=dev_index, q_local=ql, components=list(m._local_ks),
+                ms_per_step=1e3 * dt_local / args.steps, host=os.uname().nodename, pid=os.getpid())
+    try:
+        pr = torch.cuda.get_device_properties(dev_index)
+        mine['device_name'] = pr.name
+        mine['pci_bus_id'] = '%04x:%02x:%02x' % (getattr(pr, 'pci_domain_id', 0), getattr(pr, 'pci_bus_id', -1) & 0xff,
+                                                  getattr(pr, 'pci_device_id', 0))
+        mine['device_uuid'] = str(getattr(pr, 'uuid', ''))
+    except Exception as e:      # never lose the line over a missing attribute
+        mine['device_name'] = 'unknown (%s)' % e
     if not args.no_stages:
         m.loss_and_grad(pts[0])          # collective: every rank takes part (leaves theta_0 resident)
-    if rank == 0 and not args.no_stages and m._engine is not None:
+    st = None
+    if not args.no_stages and m._engine is not None:
         st = stage_times(m)
+        esz = 8 if dtype == 'float64' else 4
+        mine['stages_ms'] = st
+        mine['stage_tflops'] = {k: ql * n ** 3 / 3.0 / (st[k] * 1e-3) / 1e12 for k in ('potrf', 'trtri', 'lauum')}
+        mine['stage_frac_of_peak'] = {k: v / peak for k, v in mine['stage_tflops'].items()}
+        mine['build_gbs'] = ql * (n * n / 2.0) * esz / (st['build'] * 1e-3) / 1e9
+        mine['path_tflops'] = ql * float(n) ** 3 / (dt_local / args.steps) / 1e12
+        mine['path_frac_of_mfma_peak'] = mine['path_tflops'] / peak
+
+    # ---- the collective on its own: the all-reduce of the (P+3)-vector, device-resident, timed alone ----
+    allreduce_us = None
+    if world > 1:
+        width = 3 + q * d + 2 * q + p
+        t = torch.zeros(width, dtype=torch.float64, device='cuda' if args.backend == 'nccl' else 'cpu')
+        for _ in range(20):
+            dist.all_reduce(t)
+        barrier()
+        samples = []
+        for _ in range(5):
+            t0 = time.perf_counter()
+            for _ in range(100):
+                dist.all_reduce(t)
+            torch.cuda.synchronize()
+            samples.append((time.perf_counter() - t0) / 100 * 1e6)
+        allreduce_us = float(np.median(samples))
+    ranks = [mine]
+    if world > 1:
+        ranks = [None] * world
+        dist.all_gather_object(ranks, mine)
+    out['dist'] = dict(backend=(str(dist.get_backend()) if world > 1 else 'none (single rank: no collective on the path)'),
+                       world_size=(dist.get_world_size() if world > 1 else 1), launched_gpus=args.gpus,
+                       visible_devices=ndev, allreduce_us=allreduce_us,
+                       allreduce_note='median of 5 x 100 in-place all_reduce(sum) of the %d-double vector, alone on the stream'
+                                      % (3 + q * d + 2 * q + p) if world > 1 else None,
+                       distinct_devices=len({(r.get('host'), r.get('pci_bus_id'), r.get('device_index')) for r in ranks}),
+                       ranks=ranks)
+
+    # ---- wall-clock fit() of the same configuration (the metric names it; lcgp.py:537-540), all ranks in lock-step ----
+    if not args.no_fit and dtype == 'float64':       # (the float32 configuration's fit is a minute of evaluations: tools/fit_wallclock.py)
+        mf = LCGP(y=y, x=x, q=cfg['q'], submethod=cfg['submethod'], dtype=dtype, device='cuda:%d' % dev_index)
+        mf._get_engine()
+        barrier()
+        t0 = time.perf_counter()
+        mf.fit()
+        barrier()
+        t_fit = time.perf_counter() - t0
+        x0 = np.random.default_rng(11).uniform(0.0, 1.0, (2000, d))
+        t0 = time.perf_counter()
+        mf.predict(x0)
+        barrier()
+        t_pred = time.perf_counter() - t0
+        res = mf.opt_result
+        out['fit'] = dict(fit_wallclock_s=t_fit, iterations=int(res.nit), evaluations=int(res.nfev), final_loss=float(res.fun),
+                          converged=bool(res.success), message=str(res.message),
+                          predict_2000_wallclock_s=t_pred,
+                          note='LCGP(...).fit() from the initial parameters (scipy L-BFGS-B, defaults) on this run\'s ranks; '
+                               'the reference algorithm needs one cpu_baseline evaluation per L-BFGS-B evaluation')
+        log('fit: %.3f s, %d iterations, %d evaluations, final loss %.6g' % (t_fit, res.nit, res.nfev, res.fun))
+        del mf
+
+    if rank == 0 and st is not None:
         log('stages (ms): %s' % st)
-        ql = len(m._local_ks)
         out['stages_ms'] = st
         # dominant kernel: the single-launch LAUUM (tile_gemm<OP_LAUUM>): A^-1 = W^T W, n^3/3 flops per component
         fl = ql * float(n) ** 3 / 3.0
@@ -259,16 +351,24 @@ def main():
                 traffic = tj.get('tile_gemm_lauum_bytes_per_launch')
         except Exception:
             pass
+        sched = _hip.default_sched()
+        nb2 = (n + 127) // 128
+        progressive = ql * nb2 * (nb2 + 1) // 2 <= sched.progressive_tiles
         out['roofline'] = dict(bound='mfma', kernel='tile_gemm<double, OP_LAUUM> (A^-1 = W^T W with z = A^-1 b in its epilogue, one launch per evaluation; '
                                                     'lcgp_lauum enqueues the same launch)',
                                achieved=fl / (st['lauum'] * 1e-3) / 1e12, peak=peak, unit='TFLOP/s',
                                frac=fl / (st['lauum'] * 1e-3) / 1e12 / peak, traffic=traffic,
-                               flops_per_launch=fl, launch_ms=st['lauum'])
-        out['stage_tflops'] = dict(potrf=ql * n ** 3 / 3.0 / (st['potrf'] * 1e-3) / 1e12,
-                                   trtri=ql * n ** 3 / 3.0 / (st['trtri'] * 1e-3) / 1e12,
-                                   lauum=fl / (st['lauum'] * 1e-3) / 1e12)
-        esz = 8 if dtype == 'float64' else 4
-        out['build_gbs'] = ql * (n * n / 2.0) * esz / (st['build'] * 1e-3) / 1e9     # lower tiles only are written
+                               flops_per_launch=fl, launch_ms=st['lauum'],
+                               launched_by_the_timed_path=not progressive,
+                               note=None if not progressive else
+                               'with %d component(s) on this rank the timed path forms the inverse behind the factorisation '
+                               '(progressive filler jobs), not with this launch; it is timed here on its own' % ql)
+        # the stage groups beside it, each against the same peak (the factorisation is the one furthest below it)
+        out['roofline_stages'] = {k: dict(bound='mfma', flops=ql * n ** 3 / 3.0, ms=st[k], achieved=mine['stage_tflops'][k],
+                                          peak=peak, unit='TFLOP/s', frac=mine['stage_frac_of_peak'][k])
+                                  for k in ('potrf', 'trtri', 'lauum')}
+        out['stage_tflops'] = mine['stage_tflops']
+        out['build_gbs'] = mine['build_gbs']     # lower tiles only are written
         if args.predict > 0:
             # (the stage passes above re-ran build / factorisation / inverse at the resident theta_0: L^-1 and z are consistent)
             pr = predict_leg(m, args.predict)
@@ -278,7 +378,7 @@ def main():
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         log('cpu baseline (bounded sample) ...')
-        base, pieces, ns = cpu_baseline(m)
+        base, pieces, ns = cpu_baseline(m, repeats=args.cpu_repeats)
         out['cpu_baseline'] = base
         # parity gate in the same run, same sample: component 0, HIP path vs the Cholesky-form oracle
         # (NLL 1e-6 relative, gradient 1e-5 relative to max |g|)

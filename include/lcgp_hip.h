@@ -142,12 +142,14 @@ int lcgp_nll_grad(void* stream, int dtype, int n, int d, int p, int q_local,
 /* Assembles this rank's share of the vector the ranks all-reduce (in the reference the sum over
  * k of lcgp.py:650-661 and the gradient tape's accumulation), on the device, in a fixed summation order:
  *   vec = [ sum_k (half_logdet_k - quad_k/(2 D_k)) | sum_k info_k | g_ell (q_total x d) | g_scale (q_total) |
- *           g_nug (q_total) | g_sigma (p) ]                          width lcgp_partial_width(d, p, q_total)
+ *           g_nug (q_total) | g_sigma (p) | guard ]                  width lcgp_partial_width(d, p, q_total)
  * with g_sigma_a = sum_k psi_k[a] gsig_k[a] / (2 D_k) over the LOCAL components; the slots of component i of
  * this rank are written at its global index comp[i] (device ints), all other slots are zeroed.  q_local may
- * be 0 (a rank without components contributes zeros). */
+ * be 0 (a rank without components contributes zeros).  `guard` (device, one double, or NULL = 0) is copied into the
+ * last slot: the caller puts a hash of the parameter vector it evaluated there and compares the all-reduced value
+ * with world_size x its own -- ranks running the optimiser in lock-step detect a drift at the first evaluation. */
 int lcgp_pack_partial(void* stream, int d, int p, int q_local, int q_total, const int* comp,
-                      const double* theta, const double* out, double* vec);
+                      const double* theta, const double* out, const double* guard, double* vec);
 
 /* K6 prediction (lcgp.py:808-859 / 864-930 with the caches of 685-803): for local component k and
  * n0 new inputs x0 (already standardised) computes

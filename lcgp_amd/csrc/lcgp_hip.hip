@@ -2127,17 +2127,21 @@ int do_nll_grad(hipStream_t st, const Ws& w, const lcgp_sched& sc, const void* x
 }
 
 // The rank's share of the reduced vector, assembled on the device (one workgroup, fixed summation order):
-//   vec = [ sum_k (half_logdet_k - quad_k / (2 D_k)) | sum_k info_k | g_ell (q x d) | g_scale (q) | g_nug (q) | g_sigma (p) ]
+//   vec = [ sum_k (half_logdet_k - quad_k / (2 D_k)) | sum_k info_k | g_ell (q x d) | g_scale (q) | g_nug (q) | g_sigma (p) | guard ]
 // component-local slots are written at the GLOBAL component index comp[i]; g_sigma_a = sum_k psi_k[a] gsig_k[a] / (2 D_k).
+// guard: a word of the caller's (a hash of the parameter vector the rank evaluated) that travels through the all-reduce in
+// the last slot, so that ranks which have drifted apart are detected at the first evaluation instead of diverging.
 __global__ __launch_bounds__(256) void pack_partial_kernel(int d, int p, int q_local, int q_total,
                                                            const int* __restrict__ comp, const double* __restrict__ theta,
-                                                           const double* __restrict__ out, double* __restrict__ vec) {
+                                                           const double* __restrict__ out, const double* __restrict__ guard,
+                                                           double* __restrict__ vec) {
     const int tid = threadIdx.x;
     const int tw = d + 3 + p, ow = d + 5 + p;
     const int off_s = 2 + q_total * d, off_n = off_s + q_total, off_g = off_n + q_total;
     for (int e = tid; e < off_g; e += 256) vec[e] = 0.0;
     __syncthreads();
     if (tid == 0) {
+        vec[off_g + p] = guard ? guard[0] : 0.0;
         double v = 0.0, bad_sum = 0.0;
         for (int i = 0; i < q_local; ++i) {
             const double* o = out + (size_t)i * ow;
@@ -2243,7 +2247,7 @@ const char* lcgp_source_hash(void) { return LCGP_SRC_HASH; }
 const char* lcgp_last_error(void) { return g_err; }
 int lcgp_theta_width(int d, int p) { return d + 3 + p; }
 int lcgp_out_width(int d, int p) { return d + 5 + p; }
-int lcgp_partial_width(int d, int p, int q_total) { return 2 + q_total * d + 2 * q_total + p; }
+int lcgp_partial_width(int d, int p, int q_total) { return 3 + q_total * d + 2 * q_total + p; }
 
 int lcgp_sched_default(lcgp_sched* sched) {
     if (!sched) return bad("sched is NULL");
@@ -2390,12 +2394,12 @@ int lcgp_nll_grad(void* stream, int dtype, int n, int d, int p, int q_local, con
 }
 
 int lcgp_pack_partial(void* stream, int d, int p, int q_local, int q_total, const int* comp, const double* theta,
-                      const double* out, double* vec) {
+                      const double* out, const double* guard, double* vec) {
     if (d < 1 || d > DMAX || p < 1) return bad("d must be in [1, 32], p >= 1");
     if (q_local < 0 || q_total < 1 || q_local > q_total) return bad("need 0 <= q_local <= q_total, q_total >= 1");
     if (!vec || (q_local > 0 && (!comp || !theta || !out))) return bad("NULL pointer");
     hipLaunchKernelGGL(pack_partial_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, d, p, q_local, q_total, comp, theta,
-                       out, vec);
+                       out, guard, vec);
     CHECK_LAUNCH("pack_partial_kernel");
     return 0;
 }

@@ -58,10 +58,13 @@ class HotPathEngine:
             self.tw = self.lib.lcgp_theta_width(self.d, self.p)
             self.ow = self.lib.lcgp_out_width(self.d, self.p)
             self.pw = self.lib.lcgp_partial_width(self.d, self.p, self.q_total)
-            self.theta_dev = torch.zeros((self.q_local, self.tw), dtype=torch.float64, device=self.device)
+            # one upload per evaluation: the theta rows and, behind them, the guard word of the lock-step check
+            self._theta_flat = torch.zeros(self.q_local * self.tw + 1, dtype=torch.float64, device=self.device)
+            self.theta_dev = self._theta_flat[:self.q_local * self.tw].view(self.q_local, self.tw)
+            self.guard_dev = self._theta_flat[self.q_local * self.tw:]
             # two pinned staging rows used alternately: the H2D copy of one evaluation may still be in flight when the
             # host packs the next one (evaluate() itself synchronises, enqueue-style callers do not)
-            self._theta_pin = [torch.zeros((self.q_local, self.tw), dtype=torch.float64).pin_memory() for _ in range(2)]
+            self._theta_pin = [torch.zeros(self.q_local * self.tw + 1, dtype=torch.float64).pin_memory() for _ in range(2)]
             self._pin_event = [None, None]
             self._pin_next = 0
             self.out_dev = torch.zeros((self.q_local, self.ow), dtype=torch.float64, device=self.device)
@@ -80,16 +83,17 @@ class HotPathEngine:
     def _sched(self):
         return None if self.sched is None else C.byref(self.sched)
 
-    def upload_theta(self, theta_rows):
+    def upload_theta(self, theta_rows, guard=0.0):
         torch = self.torch
         theta_rows = np.asarray(theta_rows, dtype=np.float64).reshape(self.q_local, self.tw)
         i = self._pin_next
         self._pin_next ^= 1
         if self._pin_event[i] is not None:
             self._pin_event[i].synchronize()      # the copy that last read this staging buffer has completed
-        self._theta_pin[i].copy_(torch.from_numpy(theta_rows))
+        self._theta_pin[i][:-1].copy_(torch.from_numpy(theta_rows.reshape(-1)))
+        self._theta_pin[i][-1] = float(guard)
         with torch.cuda.device(self.device):
-            self.theta_dev.copy_(self._theta_pin[i], non_blocking=True)
+            self._theta_flat.copy_(self._theta_pin[i], non_blocking=True)
             ev = torch.cuda.Event()
             ev.record(torch.cuda.current_stream(self.device))
         self._pin_event[i] = ev
@@ -110,15 +114,15 @@ class HotPathEngine:
         self.enqueue()
         return self.out_dev.cpu().numpy()
 
-    def evaluate_partial(self, theta_rows):
+    def evaluate_partial(self, theta_rows, guard=0.0):
         """theta rows -> this rank's share of the reduced vector, LEFT ON THE DEVICE (lcgp_pack_partial): the caller
-        all-reduces it in place over the ranks (RCCL) and copies it to the host once."""
-        self.upload_theta(theta_rows)
+        all-reduces it in place over the ranks (RCCL) and copies it to the host once.  `guard` travels in its last slot."""
+        self.upload_theta(theta_rows, guard)
         self.enqueue()
         with self.torch.cuda.device(self.device):
             _hip.check(self.lib.lcgp_pack_partial(self._stream(), self.d, self.p, self.q_local, self.q_total,
                                                   self._p(self.comp_dev), self._p(self.theta_dev), self._p(self.out_dev),
-                                                  self._p(self.partial_dev)), "lcgp_pack_partial")
+                                                  self._p(self.guard_dev), self._p(self.partial_dev)), "lcgp_pack_partial")
         return self.partial_dev
 
     def is_current(self, theta_rows):

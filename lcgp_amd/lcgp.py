@@ -17,6 +17,8 @@ Deliberate differences from the reference, all documented in DESIGN.md:
 """
 from __future__ import annotations
 
+import zlib
+
 import numpy as np
 import scipy.optimize as sopt
 import torch
@@ -434,11 +436,22 @@ class LCGP:
         with np.errstate(over='ignore', divide='ignore'):
             sig_eff = np.exp(0.5 * ls2_b) / self._std
             rows = self._theta_rows(sig_eff) if eng is not None else None
+        # Lock-step guard: every rank runs its own L-BFGS-B on the all-reduced numbers, no iterate is ever broadcast.
+        # A hash of the parameter vector this rank is evaluating rides in the last slot of the vector; after the sum it must
+        # equal world_size x the local one (integers below 2^32: exact in float64), or some rank has drifted -- then
+        # EVERY rank raises here, after the same collective, instead of waiting forever in a later one.
+        guard = float(zlib.crc32(u_now.tobytes()))
         if eng is not None:
-            part = eng.evaluate_partial(rows)
+            part = eng.evaluate_partial(rows, guard)
         else:
-            part = self._zeros_on_device(2 + q * d + 2 * q + p)
+            part = self._zeros_on_device(3 + q * d + 2 * q + p)
+            part[-1] = guard
         vec = _dist.reduce_to_host(part, self._group)
+        world = _dist.rank_world(self._group)[1]
+        if vec[-1] != world * guard:
+            raise RuntimeError('lcgp_amd: the ranks are no longer in lock-step (the parameter vectors they evaluated differ: '
+                               'guard sum %.17g != %d x %.17g); every rank stops here' % (vec[-1], world, guard))
+        vec = vec[:-1]
         if vec[1] != 0 or not np.isfinite(vec[0]):
             raise np.linalg.LinAlgError(
                 'I + D_k C_k is not numerically positive definite at the current parameters (info=%g)' % vec[1])

@@ -47,6 +47,24 @@ def main():
         want = o.predict(x0)
         for a, b in zip(got, want):
             np.testing.assert_allclose(a.numpy(), b, rtol=1e-7, atol=1e-9)
+    # lock-step guard: one rank evaluates a parameter vector that differs by ONE ULP in one entry -- every rank must
+    # raise at that evaluation (after the same collective), not hang in a later one; both can carry on afterwards
+    x, y = synth.make_full(24, 30, 2, 3, 2)
+    m = patch_engine(LCGP(y=y, x=x, q=2))
+    u = m._get_flat().copy()
+    m.loss_and_grad(u)
+    ub = u.copy()
+    if rank == 1:
+        ub[3] = np.nextafter(ub[3], np.inf)
+    try:
+        m.loss_and_grad(ub)
+        raise AssertionError('rank %d did not notice the drift' % rank)
+    except RuntimeError as e:
+        assert 'lock-step' in str(e)
+    v_again, _ = m.loss_and_grad(u)          # still usable, still in step
+    both = [None, None]
+    dist.all_gather_object(both, float(v_again))
+    assert both[0] == both[1]
     # q < world: rank 1 holds no component and still takes part in the collectives
     x, y = synth.make_full(23, 30, 2, 3, 1)
     m = patch_engine(LCGP(y=y, x=x, q=1))

@@ -5,6 +5,7 @@ so these vectors come from the oracle, which is pinned by the reference's stored
 (KAT-1 / KAT-2) and by the cross-identities in tests/test_oracle_identities.py.
 
     python tests/golden/make_golden.py            # small cases  -> lcgp_golden.npz        (seconds)
+    python tests/golden/make_golden.py --ragged   # n = 4000 (not a multiple of any tile size), q = 2 -> lcgp_golden_ragged.npz
     python tests/golden/make_golden.py --large    # BASELINE.json's full-size configurations -> lcgp_golden_large.npz
                                                   # (n=4096 q=8 fp64; rep n_unique=2048 x 5; the 4096-point prefix of
                                                   #  the n=16384 fp32 configuration in fp64) -- about 5 minutes of CPU
@@ -58,6 +59,14 @@ def large_case_models():
         np.random.default_rng(40).uniform(0, 1, (10, cfg['d']))
 
 
+def ragged_case_models():
+    """A headline-scale size that is NOT a multiple of the tile sizes: n = 4000 pads to 4096 (identity padding inside the
+    last 128-tile, filler tiles, the epilogue of the one-launch A^-1 = W^T W); two components = the 4-GPU share."""
+    x, y = synth.make_full(4000, 4000, 6, 8, 2)
+    yield 'ragged_n4000', 7, orc.OracleLCGP(y=y, x=x, q=2, submethod='full'), \
+        np.random.default_rng(70).uniform(0, 1, (10, 6))
+
+
 def generate(cases, fname):
     out = {}
     for name, c, m, x0 in cases:
@@ -86,7 +95,9 @@ def generate(cases, fname):
 
 
 def main():
-    if '--large' in sys.argv[1:]:
+    if '--ragged' in sys.argv[1:]:
+        generate(ragged_case_models(), 'lcgp_golden_ragged.npz')
+    elif '--large' in sys.argv[1:]:
         generate(large_case_models(), 'lcgp_golden_large.npz')
     else:
         generate(case_models(), 'lcgp_golden.npz')

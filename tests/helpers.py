@@ -38,13 +38,14 @@ class OracleEngine:
         self._state = state
         return out
 
-    def evaluate_partial(self, theta_rows):
+    def evaluate_partial(self, theta_rows, guard=0.0):
         """What lcgp_pack_partial assembles on the device (include/lcgp_hip.h), as a CPU torch tensor."""
         import torch
         theta_rows = np.asarray(theta_rows, np.float64)
         out = self.evaluate(theta_rows)
         d, p, q = self.d, self.p, self.q_total
-        vec = np.zeros(2 + q * d + 2 * q + p)
+        vec = np.zeros(3 + q * d + 2 * q + p)
+        vec[-1] = guard
         for row, th, k in zip(out, theta_rows, self.comp_ids):
             D, psi = th[d + 2], th[d + 3:]
             vec[0] += row[0] - row[1] / (2.0 * D)
@@ -52,7 +53,7 @@ class OracleEngine:
             vec[2 + k * d:2 + (k + 1) * d] = row[3:3 + d]
             vec[2 + q * d + k] = row[3 + d]
             vec[2 + q * d + q + k] = row[4 + d]
-            vec[2 + q * d + 2 * q:] += 0.5 * psi * row[5 + d:5 + d + p] / D
+            vec[2 + q * d + 2 * q:-1] += 0.5 * psi * row[5 + d:5 + d + p] / D
         return torch.as_tensor(vec)
 
     def predict_device(self, x0s, same=False):

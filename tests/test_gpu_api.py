@@ -185,9 +185,9 @@ def test_predict_after_fit_reuses_the_factorisation():
     count = {'n': 0}
     real = eng.evaluate_partial
 
-    def spy(theta):
+    def spy(theta, guard=0.0):
         count['n'] += 1
-        return real(theta)
+        return real(theta, guard)
     eng.evaluate_partial = spy
     m.predict(x[:7])
     assert count['n'] == 0

@@ -305,7 +305,7 @@ def test_c_abi_library_exports_every_declared_symbol():
     assert nbytes.value >= 3 * 8 * 4096 * 4096 * 8
     assert lib.lcgp_workspace_bytes(0, 4096, 99, 64, 8, C.byref(nbytes)) < 0      # d > 32 refused
     assert b'd must be' in lib.lcgp_last_error()
-    assert lib.lcgp_partial_width(6, 64, 8) == 2 + 8 * 6 + 2 * 8 + 64
+    assert lib.lcgp_partial_width(6, 64, 8) == 3 + 8 * 6 + 2 * 8 + 64      # ... + the lock-step guard word
     sc = _hip.default_sched()                   # schedule parameters travel per call: the library has no setters
     assert sc.outer_blocks == 0 and sc.fill_leaf > 0 and sc.syrk_small_tiles > 0
     assert not any(n.startswith(('lcgp_set', 'lcgp_shutdown')) for n in declared)
@@ -369,9 +369,9 @@ def test_fit_backs_off_from_a_non_positive_definite_trial_point():
     real = eng.evaluate_partial
     calls = {'n': 0, 'bad': 0}
 
-    def flaky(theta_rows):
+    def flaky(theta_rows, guard=0.0):
         calls['n'] += 1
-        part = real(theta_rows)
+        part = real(theta_rows, guard)
         if calls['n'] in (3, 4):                 # two consecutive trial points "fail" (info = 7 on component 0)
             calls['bad'] += 1
             part = part.clone()
@@ -388,7 +388,7 @@ def test_fit_backs_off_from_a_non_positive_definite_trial_point():
     eng.evaluate_partial = real
     assert float(m.loss()) < before
     # outside fit() the failure is an exception
-    eng.evaluate_partial = lambda th: (lambda p: (p.__setitem__(1, 3.0), p)[1])(real(th).clone())
+    eng.evaluate_partial = lambda th, guard=0.0: (lambda p: (p.__setitem__(1, 3.0), p)[1])(real(th, guard).clone())
     with pytest.raises(np.linalg.LinAlgError):
         m.loss()
     # ... and a failure at the very first evaluation of fit() has no value to back off to: it raises as well
