@@ -44,6 +44,17 @@ def main():
         for a, b in zip(m.predict(x0), o.predict(x0)):
             np.testing.assert_allclose(a.numpy(), b, rtol=1e-6, atol=1e-8)
         assert np.all(np.isfinite(m.CinvMs.numpy()))
+    # lock-step guard through the real engines: a one-ulp difference of ONE entry on ONE rank raises on both
+    u = m._get_flat().copy()
+    ub = u.copy()
+    if rank == 0:
+        ub[1] = np.nextafter(ub[1], -np.inf)
+    try:
+        m.loss_and_grad(ub)
+        raise AssertionError('rank %d did not notice the drift' % rank)
+    except RuntimeError as e:
+        assert 'lock-step' in str(e)
+    m.loss_and_grad(u)
     # q < world: rank 1 holds no component, has no engine, and still takes part in every collective
     x, y = synth.make_full(33, 200, 2, 3, 1)
     m = LCGP(y=y, x=x, q=1, device="cuda:0")
@@ -55,6 +66,16 @@ def main():
     assert abs(v1 - v2) <= 1e-6 * abs(v2) and np.max(np.abs(g1 - g2)) <= 1e-5 * np.max(np.abs(g2))
     np.testing.assert_allclose(m.predict(x[:5])[0].numpy(), o.predict(x[:5])[0], rtol=1e-6, atol=1e-8)
     assert m.CinvMs.shape == (1, 200)
+    # ... and the guard works when the drifting rank is the one WITHOUT an engine
+    u = m._get_flat().copy()
+    ub = u.copy()
+    if rank == 1:
+        ub[0] = np.nextafter(ub[0], np.inf)
+    try:
+        m.loss_and_grad(ub)
+        raise AssertionError('rank %d did not notice the drift' % rank)
+    except RuntimeError as e:
+        assert 'lock-step' in str(e)
     dist.barrier()
     dist.destroy_process_group()
     print("RANK %d OK" % rank)

@@ -69,6 +69,71 @@ def test_cfg3_headline_size_nll_every_gradient_entry_and_predictions():
     _check_predictions(m, 'cfg3_n4096', 1e-6, 1e-8)
 
 
+class _RankShares:
+    """Stands in for the model's engine: the components split over `world` engines exactly as `world` ranks would hold
+    them (k -> rank k mod world; every engine is the real HIP engine with that rank's q_local, i.e. that rank's tile-size
+    thresholds, filler plan and -- with one or two components -- the inverse formed behind the chain), the partial vectors
+    summed as the all-reduce would."""
+
+    def __init__(self, m, world):
+        from lcgp_amd.engine import HotPathEngine
+        self.m, self.world = m, world
+        self.device = None
+        q = int(m.q)
+        self.ks = [list(range(r, q, world)) for r in range(world)]
+        self.engines = [HotPathEngine(m.x.numpy(), m.y.numpy(), None, len(ks), 'float64', 'cuda:0', comp_ids=ks, q_total=q)
+                        for ks in self.ks]
+
+    def evaluate_partial(self, theta_rows, guard=0.0):
+        total = None
+        for eng, ks in zip(self.engines, self.ks):
+            part = eng.evaluate_partial(theta_rows[ks], guard).cpu()
+            total = part.clone() if total is None else total + part
+        total[-1] = guard               # (one rank's view: the model divides by its own world size of 1)
+        return total
+
+
+@pytest.mark.parametrize('world', [2, 4, 8])
+def test_cfg3_rank_shares_sum_to_the_golden(world):
+    """The 2-, 4- and 8-GPU shares of the headline configuration (q_local = 4, 2, 1: different tile-size thresholds, and
+    from two components down the progressive inverse) evaluated by separate engines on this one GPU and summed like the
+    all-reduce: NLL and all 128 gradient entries against the cfg3 golden (lcgp.py:635-666; fan-out lcgp.py:718-720)."""
+    x, y, cfg = synth.make_config(3)
+    m = LCGP(y=y, x=x, q=cfg['q'])
+    m._get_engine()
+    m._engine = _RankShares(m, world)
+    assert [e.q_local for e in m._engine.engines] == [8 // world] * world
+    _check_points(m, 'cfg3_n4096', NLL_TOL, GRAD_TOL)
+
+
+def test_ragged_n4000_against_the_golden():
+    """n = 4000 is no multiple of 64 or 128: identity padding INSIDE the last 128-tile, filler tiles, the 128-tile A^-1
+    launch with its z epilogue (classic schedule) and the progressive inverse (default at q = 2 here? no: forced both ways)
+    against oracle values; predictions with the full covariance as well."""
+    from lcgp_amd import _hip
+    gold = np.load(os.path.join(HERE, 'golden', 'lcgp_golden_ragged.npz'))
+    x, y = synth.make_full(4000, 4000, 6, 8, 2)
+    m = LCGP(y=y, x=x, q=2)
+    eng = m._get_engine()
+    for fields in (dict(progressive_tiles=0), dict(progressive_tiles=1 << 30),
+                   dict(progressive_tiles=0, lauum_small_tiles=0, trtri_small_tiles=0, trtri_level_small=0, syrk_small_tiles=1)):
+        sc = _hip.default_sched()
+        for k, v in fields.items():
+            setattr(sc, k, v)
+        eng.sched = sc
+        for i, u in enumerate(gold['ragged_n4000/u']):
+            v, g = m.loss_and_grad(u)
+            want_v, want_g = gold['ragged_n4000/nll'][i], gold['ragged_n4000/grad'][i]
+            assert abs(v - want_v) <= NLL_TOL * abs(want_v), (fields, i, v, want_v)
+            assert np.max(np.abs(g - want_g)) <= GRAD_TOL * np.max(np.abs(want_g)), (fields, i)
+        m._set_flat(gold['ragged_n4000/u'][1])
+        got = m.predict(gold['ragged_n4000/x0'], return_fullcov=True)
+        for key, arr in zip(('ypred', 'ypredvar', 'yconfvar', 'fullcov'), got):
+            want = gold['ragged_n4000/' + key]
+            np.testing.assert_allclose(arr.numpy(), want, rtol=1e-6, atol=1e-8 * np.max(np.abs(want)), err_msg=key)
+    eng.sched = None
+
+
 def test_cfg5_replicated_2048x5_nll_gradient_and_predictions():
     """n_unique=2048 x 5 replicates, d=3, p=12 -> q=6, submethod='rep', fp64 (lcgp.py:554-630, 864-930)."""
     x, y, cfg = synth.make_config(5)

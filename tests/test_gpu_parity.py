@@ -237,7 +237,8 @@ def test_cfg3_inverse_times_matrix_is_identity_on_sampled_columns(cfg3):
 
 
 def test_few_components_many_tiles_inverse_and_derivative():
-    """One rank's share of a multi-GPU run: q_local = 2 at n = 2304 (a ragged 128-tile edge).  With fewer than 4
+    """One rank's share of a multi-GPU run: q_local = 2 at n = 2304 (= 18 x 128: whole 128-tiles, a last outer panel of
+    two 64-blocks; sizes that are NOT multiples of the tiles are in tests/test_gpu_configs.py: n = 4000).  With fewer than 4
     components the tiles of the triangular products are enumerated in a different order (every other group of 256
     backwards, lcgp_hip.hip gemm_body) once a launch has more than 256 of them, which only sizes like this reach:
     A^-1 A = I on sampled columns of both components and the directional derivative of the NLL check the inverse and
