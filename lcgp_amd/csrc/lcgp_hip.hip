@@ -53,7 +53,7 @@ struct Ws {
     size_t esz;
     size_t mat;          // elements per matrix
     char* base;
-    size_t off_M, off_W, off_V, off_b, off_z, off_part, off_logdet, off_info, total;
+    size_t off_M, off_W, off_V, off_b, off_z, off_part, off_cpart, off_c, off_logdet, off_info, total;
     int ntile_lower;
 };
 
@@ -76,6 +76,9 @@ inline Ws carve(int dtype, int n, int d, int p, int q, void* base) {
     w.off_z = o; o = align256(o + (size_t)w.npad * q * w.esz);
     w.off_part = o; o = align256(o + (size_t)w.ntile_lower * q * 2 * TS * sizeof(double));   // symv partials (2 x 64 per
                                                                                           // tile), then gradient partials
+    // float32 only: c = (C o s s^T) z in double (per-tile partials, then the vector), see grad_kernel
+    w.off_cpart = o; o = align256(o + (dtype == LCGP_F64 ? 0 : (size_t)w.ntile_lower * q * 2 * TS * sizeof(double)));
+    w.off_c = o; o = align256(o + (dtype == LCGP_F64 ? 0 : (size_t)w.npad * q * sizeof(double)));
     w.off_logdet = o; o = align256(o + (size_t)q * sizeof(double));
     w.off_info = o; o = align256(o + (size_t)q * sizeof(int));
     w.total = o;
@@ -1598,12 +1601,21 @@ __device__ __forceinline__ void gsig_body(int a, int k, int n, int npad, int d, 
     if (tid == 0) out[(size_t)k * (d + 5 + p) + 5 + d + a] = s;
 }
 
+// float32 (CZ): the quadratic form b^T (b - z) and the noise gradient Y (b - z) cancel when A is close to the identity
+// (z ~ b), and an fp32 z carries an error of 6e-8 |b| -- the same size as b - z itself in that regime (the NLL of the
+// n = 16384 configuration moved by 1.6e-4 relative, enough to end an L-BFGS-B run early or late).  A z = b gives
+//   b - z = D (C o s s^T) z   exactly,
+// whose error is D C (error of z): small exactly where the difference cancels.  The kernel matrix is recomputed tile by
+// tile here anyway, so the tiles also emit the symmetric matrix-vector partials of c = (C o s s^T) z in double:
+//   cpart[tile][0][i] = sum_j Cs_ij z_j  (rows of the tile),  cpart[tile][1][j] = sum_{i != j} Cs_ij z_i  (its columns)
 template <typename T, int DD>
 __global__ __launch_bounds__(256) void grad_kernel(const T* __restrict__ V, size_t mat, int n, int npad, int d, int p,
                                                    const T* __restrict__ x, const T* __restrict__ sr,
                                                    const T* __restrict__ z, const double* __restrict__ theta,
                                                    double* __restrict__ part, int ntile, const T* __restrict__ Y,
-                                                   const T* __restrict__ bvec, double* __restrict__ out) {
+                                                   const T* __restrict__ bvec, double* __restrict__ out,
+                                                   double* __restrict__ cpart) {
+    constexpr bool CZ = sizeof(T) == 4;
     if ((int)blockIdx.x >= ntile) {
         gsig_body<T>(blockIdx.x - ntile, blockIdx.y, n, npad, d, p, Y, bvec, z, out);
         return;
@@ -1637,6 +1649,13 @@ __global__ __launch_bounds__(256) void grad_kernel(const T* __restrict__ V, size
     double acc[DD + 2];
 #pragma unroll
     for (int e = 0; e < DD + 2; ++e) acc[e] = 0.0;
+    double cz1[CZ ? 8 : 1], cz2[CZ ? 2 : 1];      // c partials: the thread's 8 rows (over its 2 columns), its 2 columns (over its rows)
+    if constexpr (CZ) {
+#pragma unroll
+        for (int m = 0; m < 8; ++m) cz1[m] = 0.0;
+        cz2[0] = cz2[1] = 0.0;
+    }
+    const double scale_c = th[d], nt_c = th[d + 1] / (1.0 + th[d + 1]);
     const T* Vk = V + (size_t)k * mat;
     // thread = two adjacent columns (one 16-byte load per row in fp64) x 8 rows: two independent chains per load
     const int j0 = (tid & 31) * 2;
@@ -1682,7 +1701,13 @@ __global__ __launch_bounds__(256) void grad_kernel(const T* __restrict__ V, size
                 prod = fma(prod, s, prod);
                 ssum -= s;
             }
-            const double ge = G * exp_nonpos(ssum);
+            const double ex = exp_nonpos(ssum);
+            const double ge = G * ex;
+            if constexpr (CZ) {
+                const double cs = srr[i] * src[j] * scale_c * ((1.0 - nt_c) * (ex * prod) + (gi == gj ? nt_c : 0.0));
+                cz1[m] = fma(cs, zc[j], cz1[m]);
+                if (gi != gj) cz2[h] = fma(cs, zr[i], cz2[h]);
+            }
             double suf = 1.0;
 #pragma unroll
             for (int jj = DD - 1; jj >= 0; --jj) {
@@ -1709,6 +1734,56 @@ __global__ __launch_bounds__(256) void grad_kernel(const T* __restrict__ V, size
         double* dst = part + ((size_t)k * ntile + blockIdx.x) * (DMAX + 2);
         dst[tid] = (red[0][e] + red[1][e]) + (red[2][e] + red[3][e]);
     }
+    if constexpr (CZ) {
+        // rows: the 32 lanes of a half wave share the thread's 8 rows (butterfly); columns: the 8 row groups through LDS
+        __shared__ double c2s[8][TS];
+#pragma unroll
+        for (int m = 0; m < 8; ++m) {
+            double v = cz1[m];
+            for (int off = 16; off > 0; off >>= 1) v += __shfl_xor(v, off);
+            cz1[m] = v;
+        }
+        c2s[tid >> 5][j0] = cz2[0];
+        c2s[tid >> 5][j0 + 1] = cz2[1];
+        __syncthreads();
+        double* dst = cpart + ((size_t)k * ntile + blockIdx.x) * 2 * TS;
+        if ((tid & 31) == 0) {
+#pragma unroll
+            for (int m = 0; m < 8; ++m) dst[(tid >> 5) * 8 + m] = cz1[m];
+        }
+        if (tid < TS)
+            dst[TS + tid] = ((c2s[0][tid] + c2s[1][tid]) + (c2s[2][tid] + c2s[3][tid])) +
+                            ((c2s[4][tid] + c2s[5][tid]) + (c2s[6][tid] + c2s[7][tid]));
+    }
+}
+
+// c_R = sum_{c <= R} cpart(R, c)[0] + sum_{r >= R} cpart(r, R)[1]   (the diagonal tile's column part holds its strictly lower
+// elements only), fixed order; one workgroup per 64-row block and component
+__global__ __launch_bounds__(256) void cvec_reduce_kernel(const double* __restrict__ cpart, int ntile, int npad, int nb,
+                                                          double* __restrict__ c) {
+    __shared__ double sh[4][TS];
+    const int k = blockIdx.y, R = blockIdx.x, i = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const double* pk = cpart + (size_t)k * ntile * 2 * TS;
+    double s = 0.0;
+    for (int cc = g; cc <= R; cc += 4) s += pk[((size_t)(R * (R + 1) / 2 + cc)) * 2 * TS + i];
+    for (int r = R + g; r < nb; r += 4) s += pk[((size_t)(r * (r + 1) / 2 + R)) * 2 * TS + TS + i];
+    sh[g][i] = s;
+    __syncthreads();
+    if (g == 0) c[(size_t)k * npad + R * TS + i] = (sh[0][i] + sh[1][i]) + (sh[2][i] + sh[3][i]);
+}
+
+// float32: gsig_a = D sum_i Y[a, i] c_i   (= sum_i Y[a, i] (b_i - z_i) without the cancellation)
+template <typename T>
+__global__ __launch_bounds__(256) void gsig_c_kernel(int n, int npad, int d, int p, const T* __restrict__ Y,
+                                                     const double* __restrict__ c, const double* __restrict__ theta,
+                                                     double* __restrict__ out) {
+    __shared__ double sh[4];
+    const int a = blockIdx.x, k = blockIdx.y, tid = threadIdx.x;
+    const double* ck = c + (size_t)k * npad;
+    double s = 0.0;
+    for (int i = tid; i < n; i += 256) s += (double)Y[(size_t)a * n + i] * ck[i];
+    s = block_sum(s, sh, tid);
+    if (tid == 0) out[(size_t)k * (d + 5 + p) + 5 + d + a] = th_row(theta, d, p, k)[d + 2] * s;
 }
 
 
@@ -1717,7 +1792,8 @@ __global__ __launch_bounds__(256) void finalize_kernel(int n, int npad, int d, i
                                                        const T* __restrict__ Y, const T* __restrict__ b,
                                                        const T* __restrict__ z, const double* __restrict__ part,
                                                        const double* __restrict__ logdet, const int* __restrict__ info,
-                                                       const double* __restrict__ theta, double* __restrict__ out) {
+                                                       const double* __restrict__ theta, double* __restrict__ out,
+                                                       const double* __restrict__ cvec /*float32: (C o s s^T) z, else null*/) {
     __shared__ double sh[4];
     __shared__ double grp[256];
     __shared__ double sums[DMAX + 2];
@@ -1748,8 +1824,16 @@ __global__ __launch_bounds__(256) void finalize_kernel(int n, int npad, int d, i
     }
     grp[tid] = acc;
     double v = 0.0;
+    if (cvec) {
+        // b^T (b - z) = D b^T (C o s s^T) z: no cancellation (see grad_kernel)
+        const double* ck = cvec + (size_t)k * npad;
 #pragma unroll 4
-    for (int i = tid; i < n; i += 256) v += (double)bk[i] * ((double)bk[i] - (double)zk[i]);
+        for (int i = tid; i < n; i += 256) v += (double)bk[i] * ck[i];
+        v *= th[d + 2];
+    } else {
+#pragma unroll 4
+        for (int i = tid; i < n; i += 256) v += (double)bk[i] * ((double)bk[i] - (double)zk[i]);
+    }
     __syncthreads();
     if (tid < ne) {
         double s = 0.0;
@@ -2079,10 +2163,11 @@ int do_potri(hipStream_t st, const Ws& w, const lcgp_sched& sc, bool* z_partials
 template <typename T, int DD>
 void launch_grad(hipStream_t st, const Ws& w, const void* x, const void* sr, const double* theta, const void* Y,
                  double* out) {
-    hipLaunchKernelGGL((grad_kernel<T, DD>), dim3(w.ntile_lower + w.p, w.q), dim3(256), 0, st,
+    // (float32: the noise gradient comes from c = (C o s s^T) z after this launch, so no extra blocks here)
+    hipLaunchKernelGGL((grad_kernel<T, DD>), dim3(w.ntile_lower + (sizeof(T) == 4 ? 0 : w.p), w.q), dim3(256), 0, st,
                        (const T*)(w.base + w.off_V), w.mat, w.n, w.npad, w.d, w.p, (const T*)x, (const T*)sr,
                        (const T*)(w.base + w.off_z), theta, (double*)(w.base + w.off_part), w.ntile_lower, (const T*)Y,
-                       (const T*)(w.base + w.off_b), out);
+                       (const T*)(w.base + w.off_b), out, (double*)(w.base + w.off_cpart));
 }
 
 template <typename T>
@@ -2119,9 +2204,20 @@ int do_nll_grad(hipStream_t st, const Ws& w, const lcgp_sched& sc, const void* x
     else if (w.d <= 16) launch_grad<T, 16>(st, w, x, sr, theta, Y, out);
     else launch_grad<T, DMAX>(st, w, x, sr, theta, Y, out);
     CHECK_LAUNCH("grad_kernel");
+    const double* cvec = nullptr;
+    if constexpr (sizeof(T) == 4) {
+        double* c = (double*)(w.base + w.off_c);
+        hipLaunchKernelGGL(cvec_reduce_kernel, dim3(w.nb, w.q), dim3(256), 0, st, (const double*)(w.base + w.off_cpart),
+                           w.ntile_lower, w.npad, w.nb, c);
+        CHECK_LAUNCH("cvec_reduce_kernel");
+        hipLaunchKernelGGL((gsig_c_kernel<T>), dim3(w.p, w.q), dim3(256), 0, st, w.n, w.npad, w.d, w.p, (const T*)Y,
+                           (const double*)c, theta, out);
+        CHECK_LAUNCH("gsig_c_kernel");
+        cvec = c;
+    }
     hipLaunchKernelGGL((finalize_kernel<T>), dim3(w.q), dim3(256), 0, st, w.n, w.npad, w.d, w.p, w.ntile_lower,
                        (const T*)Y, (const T*)b, (const T*)z, (const double*)(w.base + w.off_part),
-                       (const double*)(w.base + w.off_logdet), (const int*)(w.base + w.off_info), theta, out);
+                       (const double*)(w.base + w.off_logdet), (const int*)(w.base + w.off_info), theta, out, cvec);
     CHECK_LAUNCH("finalize_kernel");
     return 0;
 }

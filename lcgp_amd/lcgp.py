@@ -70,6 +70,11 @@ class LCGP:
         self.parameter_clamp_flag = parameter_clamp_flag
         self._device = device
         self._dtype = dtype
+        self._engine64 = None            # float32 models: float64 engine for points where the float32 factorisation fails
+        self.float32_fallback = True
+        self.float32_fallbacks = 0
+        self._last_eval_float64 = False
+        self._aux_engine = None          # the engine whose workspace holds the factorisation of _u_last
         self._group = process_group
         self._engine = None
         self._u_last = None          # unconstrained vector the factorisation in the workspace belongs to
@@ -364,9 +369,10 @@ class LCGP:
     # =============================================================================================
     # the hot path (lcgp.py:537-666 + the gpflow/TF gradient tape)
     # =============================================================================================
-    def _make_engine(self):
+    def _make_engine(self, dtype=None):
         """One rank's share of the path on the GPU (raises without a GPU: no CPU fallback)."""
         from .engine import HotPathEngine
+        dtype = self._dtype if dtype is None else dtype
         rank, world = _dist.rank_world(self._group)
         self._local_ks = _dist.local_components(self.q, rank, world)
         if not self._local_ks:
@@ -375,8 +381,8 @@ class LCGP:
             sr = np.sqrt(_np(self.r))
             ybar_used = _np(self.ybar_s if self.rep_standardize_ybar else self.ybar)
             return HotPathEngine(_np(self.x_unique_s), ybar_used * sr[None, :], sr, len(self._local_ks),
-                                 self._dtype, self._device, comp_ids=self._local_ks, q_total=self.q)
-        return HotPathEngine(_np(self.x), _np(self.y), None, len(self._local_ks), self._dtype, self._device,
+                                 dtype, self._device, comp_ids=self._local_ks, q_total=self.q)
+        return HotPathEngine(_np(self.x), _np(self.y), None, len(self._local_ks), dtype, self._device,
                              comp_ids=self._local_ks, q_total=self.q)
 
     def _get_engine(self):
@@ -441,21 +447,38 @@ class LCGP:
         # equal world_size x the local one (integers below 2^32: exact in float64), or some rank has drifted -- then
         # EVERY rank raises here, after the same collective, instead of waiting forever in a later one.
         guard = float(zlib.crc32(u_now.tobytes()))
-        if eng is not None:
-            part = eng.evaluate_partial(rows, guard)
-        else:
-            part = self._zeros_on_device(3 + q * d + 2 * q + p)
-            part[-1] = guard
-        vec = _dist.reduce_to_host(part, self._group)
         world = _dist.rank_world(self._group)[1]
-        if vec[-1] != world * guard:
-            raise RuntimeError('lcgp_amd: the ranks are no longer in lock-step (the parameter vectors they evaluated differ: '
-                               'guard sum %.17g != %d x %.17g); every rank stops here' % (vec[-1], world, guard))
-        vec = vec[:-1]
+
+        def reduced(engine):
+            if engine is not None:
+                part = engine.evaluate_partial(rows, guard)
+            else:
+                part = self._zeros_on_device(3 + q * d + 2 * q + p)
+                part[-1] = guard
+            v = _dist.reduce_to_host(part, self._group)
+            if v[-1] != world * guard:
+                raise RuntimeError('lcgp_amd: the ranks are no longer in lock-step (the parameter vectors they evaluated '
+                                   'differ: guard sum %.17g != %d x %.17g); every rank stops here' % (v[-1], world, guard))
+            return v[:-1]
+
+        vec = reduced(eng)
+        if (vec[1] != 0 or not np.isfinite(vec[0])) and self._dtype == 'float32' and self.float32_fallback:
+            # The float32 factorisation broke down (I + D_k C_k has a condition number beyond single precision somewhere
+            # along a line search; the reference is float64 only).  The point is evaluated again in float64 -- on every
+            # rank: info was all-reduced -- so the optimiser sees the objective there instead of an artificial value.
+            if self._engine64 is None and eng is not None:
+                self._engine64 = self._make_engine('float64')
+            self.float32_fallbacks += 1
+            vec = reduced(self._engine64)
+            self._last_eval_float64 = True
+        else:
+            self._last_eval_float64 = False
         if vec[1] != 0 or not np.isfinite(vec[0]):
             raise np.linalg.LinAlgError(
                 'I + D_k C_k is not numerically positive definite at the current parameters (info=%g)' % vec[1])
-        self._u_last = u_now         # the workspace now holds L, L^-1, A^-1, z at these parameters
+        # the workspace of the engine that ran now holds L, L^-1, A^-1, z at these parameters
+        self._u_last = u_now
+        self._aux_engine = self._engine64 if self._last_eval_float64 else eng
         nll = vec[0] + 0.5 * np.sum(self._ysq / sig_eff ** 2) + n / 2.0 * np.sum(ls2_b - 2.0 * np.log(self._std)) \
             - 0.5 * p * self._sum_log_r
         g_b = vec[2 + q * d + 2 * q:] + n / 2.0 - 0.5 * self._ysq / sig_eff ** 2
@@ -502,6 +525,22 @@ class LCGP:
             return val, g
 
         res = sopt.minimize(fun, u0, jac=True, method='L-BFGS-B')
+        if self._dtype == 'float32':
+            # The float32 objective carries rounding noise of ~3e-7 relative, far above L-BFGS-B's default relative-reduction
+            # test (2.2e-9): a run ends when one line search returns a step inside the noise.  Restarting from the point it
+            # stopped at (fresh curvature memory) until a whole run gains less than 1e-6 relative carries on to where the
+            # float64 run ends (tests/test_gpu_configs.py: final losses within 1e-3 relative on the configs[3] prefix).
+            total_nit, total_nfev = res.nit, res.nfev
+            for _ in range(30):
+                nxt = sopt.minimize(fun, res.x, jac=True, method='L-BFGS-B')
+                total_nit += nxt.nit
+                total_nfev += nxt.nfev
+                gained = res.fun - nxt.fun
+                if nxt.fun <= res.fun:
+                    res = nxt
+                if not gained > 1e-6 * abs(res.fun):
+                    break
+            res.nit, res.nfev = total_nit, total_nfev
         self._set_flat(res.x)
         self.opt_result = res
         return
@@ -570,7 +609,8 @@ class LCGP:
         # workspace the one of the current parameter vector?
         if not self._aux_valid:
             self.compute_aux_predictive_quantities()
-        return eng
+        # (a float32 model whose factorisation failed at these parameters was evaluated by its float64 engine)
+        return self._aux_engine if eng is not None else None
 
     def _latent_predict(self, x0):
         """ghat, gvar (q, n0) for raw-scale x0 (lcgp.py:822-838 / 877-900): the local components' rows are computed
@@ -642,7 +682,7 @@ class LCGP:
 
     # ---- cache views the reference keeps as attributes (materialised from the device only when read) ----
     def _fetch_all(self, fn, width):
-        eng = self._engine
+        eng = self._aux_engine if self._engine is not None else None
         rows = np.zeros((len(self._local_ks), width), F64)
         if eng is not None:
             for i in range(len(self._local_ks)):
