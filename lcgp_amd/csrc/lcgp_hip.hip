@@ -27,7 +27,9 @@ namespace {
 
 constexpr int TS = 64;    // tile size (rows/cols of one tile)
 constexpr int KT = 16;    // k extent of one LDS stage
-constexpr int DMAX = 32;  // max input dimension handled by the fused kernels (instantiated for 2, 4, 6, 10, 16, 32)
+constexpr int DMAX = 32;  // input dimensions staged in LDS at once (the fused kernels are instantiated for 2, 4, 6, 10, 16, 32)
+constexpr int DWIDE = 126; // largest input dimension (beyond 32: chunks of 32 dimensions, grad_kernel_wide; the per-tile partial
+                           // sums of the gradient contraction hold d + 2 <= 128 doubles)
 
 typedef double d4 __attribute__((ext_vector_type(4)));
 typedef float f4 __attribute__((ext_vector_type(4)));
@@ -197,18 +199,11 @@ __global__ __launch_bounds__(256) void build_kernel(T* __restrict__ M, size_t ma
     const T c_off = (T)(D * scale * (1.0 - nt));        // multiplies C0
     const T c_diag = (T)(1.0 + D * scale * nt);         // extra term on the diagonal (times sr_i^2)
     const int tid = threadIdx.x;
-    for (int e = tid; e < TS * DD; e += 256) {             // (columns d .. DD-1 are zero: they add |0 - 0| = 0)
-        int i = e / DD, j = e - i * DD;
-        int gi = r * TS + i, gj = c * TS + i;
-        xr[i][j] = (gi < n && j < d) ? (T)((double)x[(size_t)gi * d + j] / th[j]) : (T)0;
-        xc[i][j] = (gj < n && j < d) ? (T)((double)x[(size_t)gj * d + j] / th[j]) : (T)0;
-    }
     if (tid < TS) {
         int gi = r * TS + tid, gj = c * TS + tid;
         srr[tid] = (sr && gi < n) ? sr[gi] : (T)1;
         src[tid] = (sr && gj < n) ? sr[gj] : (T)1;
     }
-    __syncthreads();
     T* Mk = M + (size_t)k * mat;
     // 4 x 4 elements per thread (16 x 16 threads per tile): every LDS read of a scaled input row/column is used four
     // times, 16 independent exp chains per thread.  Columns per thread: in fp32 four consecutive ones (one 16-byte store
@@ -225,19 +220,38 @@ __global__ __launch_bounds__(256) void build_kernel(T* __restrict__ M, size_t ma
 #pragma unroll
         for (int b = 0; b < 4; ++b) { poly[a][b] = (T)1; ssum[a][b] = (T)0; }
     constexpr int UNR = DD <= 6 ? DD : 2;          // (fully unrolled the LDS reads of all dimensions are hoisted: registers)
+    // one chunk of (at most) DD dimensions starting at d0: staged in LDS divided by ell, then accumulated
+    auto chunk = [&](const int d0) {
+        for (int e = tid; e < TS * DD; e += 256) {         // (columns beyond d are zero: they add |0 - 0| = 0)
+            int i = e / DD, j = e - i * DD;
+            int gi = r * TS + i, gj = c * TS + i;
+            xr[i][j] = (gi < n && d0 + j < d) ? (T)((double)x[(size_t)gi * d + d0 + j] / th[d0 + j]) : (T)0;
+            xc[i][j] = (gj < n && d0 + j < d) ? (T)((double)x[(size_t)gj * d + d0 + j] / th[d0 + j]) : (T)0;
+        }
+        __syncthreads();
 #pragma unroll UNR
-    for (int jj = 0; jj < DD; ++jj) {
-        T xa[4], xb[4];
+        for (int jj = 0; jj < DD; ++jj) {
+            T xa[4], xb[4];
 #pragma unroll
-        for (int a = 0; a < 4; ++a) { xa[a] = xr[i0 + a][jj]; xb[a] = xc[colof(a)][jj]; }
+            for (int a = 0; a < 4; ++a) { xa[a] = xr[i0 + a][jj]; xb[a] = xc[colof(a)][jj]; }
 #pragma unroll
-        for (int a = 0; a < 4; ++a)
+            for (int a = 0; a < 4; ++a)
 #pragma unroll
-            for (int b = 0; b < 4; ++b) {
-                const T sd = fabs(xa[a] - xb[b]);
-                poly[a][b] = fma(poly[a][b], sd, poly[a][b]);
-                ssum[a][b] -= sd;
-            }
+                for (int b = 0; b < 4; ++b) {
+                    const T sd = fabs(xa[a] - xb[b]);
+                    poly[a][b] = fma(poly[a][b], sd, poly[a][b]);
+                    ssum[a][b] -= sd;
+                }
+        }
+    };
+    if constexpr (DD == DMAX) {
+        // the widest instantiation also serves d > 32 (covmat.py:35-42 loops over any d): 32 dimensions at a time
+        for (int d0 = 0; d0 < d; d0 += DD) {
+            if (d0 > 0) __syncthreads();
+            chunk(d0);
+        }
+    } else {
+        chunk(0);
     }
 #pragma unroll
     for (int a = 0; a < 4; ++a) {
@@ -269,7 +283,7 @@ __global__ __launch_bounds__(256) void build_kernel(T* __restrict__ M, size_t ma
 
 // rectangular Matern32 (covmat.py:31-55): out (n1 x n2) = scale ((1-nt) C0 + nt I[same]) o colscale^T.
 // Parameters come either by value (host call, lcgp_matern32) or from a device theta row (predict).
-struct ThetaArg { double v[DMAX + 2]; };
+struct ThetaArg { double v[DWIDE + 2]; };
 
 template <typename T>
 __global__ __launch_bounds__(256) void cross_kernel(T* __restrict__ out, int ldo, int n1, int n2, int d,
@@ -281,41 +295,52 @@ __global__ __launch_bounds__(256) void cross_kernel(T* __restrict__ out, int ldo
     __shared__ double xr[TS][DMAX + 1];
     __shared__ double xc[TS][DMAX + 1];
     __shared__ double cs[TS];
-    __shared__ double th[DMAX + 2];
+    __shared__ double th[DWIDE + 2];
     const int r = blockIdx.y, c = blockIdx.x;
     const int tid = threadIdx.x;
     if (thp) thp += (size_t)blockIdx.z * th_stride;
     out += (size_t)blockIdx.z * out_stride;
     if (tid < d + 2) th[tid] = thp ? thp[tid] : tv.v[tid];
-    __syncthreads();
-    const double scale = th[d], nug = th[d + 1];
-    const double nt = nug / (1.0 + nug);
-    for (int e = tid; e < TS * d; e += 256) {
-        int i = e / d, j = e - i * d;
-        int gi = r * TS + i, gj = c * TS + i;
-        xr[i][j] = gi < n1 ? (double)x1[(size_t)gi * d + j] / th[j] : 0.0;
-        xc[i][j] = gj < n2 ? (double)x2[(size_t)gj * d + j] / th[j] : 0.0;
-    }
     if (tid < TS) {
         int gj = c * TS + tid;
         cs[tid] = (colscale && gj < n2) ? (double)colscale[gj] : 1.0;
     }
     __syncthreads();
+    const double scale = th[d], nug = th[d + 1];
+    const double nt = nug / (1.0 + nug);
     const int j = tid & 63;
     const int gj = c * TS + j;
+    double poly[16], ssum[16];
+#pragma unroll
+    for (int m = 0; m < 16; ++m) { poly[m] = 1.0; ssum[m] = 0.0; }
+    for (int d0 = 0; d0 < d; d0 += DMAX) {           // the dimensions in chunks of 32 (covmat.py:35-42 loops over any d)
+        const int dc = d - d0 < DMAX ? d - d0 : DMAX;
+        if (d0 > 0) __syncthreads();
+        for (int e = tid; e < TS * dc; e += 256) {
+            int i = e / dc, jj = e - i * dc;
+            int gi = r * TS + i, gjj = c * TS + i;
+            xr[i][jj] = gi < n1 ? (double)x1[(size_t)gi * d + d0 + jj] / th[d0 + jj] : 0.0;
+            xc[i][jj] = gjj < n2 ? (double)x2[(size_t)gjj * d + d0 + jj] / th[d0 + jj] : 0.0;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int m = 0; m < 16; ++m) {
+            const int i = (tid >> 6) * 16 + m;
+            for (int jj = 0; jj < dc; ++jj) {
+                double sd = fabs(xr[i][jj] - xc[j][jj]);
+                poly[m] *= 1.0 + sd;
+                ssum[m] -= sd;
+            }
+        }
+    }
+#pragma unroll
     for (int m = 0; m < 16; ++m) {
         const int i = (tid >> 6) * 16 + m;
         const int gi = r * TS + i;
         if (gi >= n1pad || gj >= n2pad) continue;
         double v = 0.0;
         if (gi < n1 && gj < n2) {
-            double poly = 1.0, ssum = 0.0;
-            for (int jj = 0; jj < d; ++jj) {
-                double s = fabs(xr[i][jj] - xc[j][jj]);
-                poly *= 1.0 + s;
-                ssum -= s;
-            }
-            double c0 = poly * exp_nonpos(ssum);
+            double c0 = poly[m] * exp_nonpos(ssum[m]);
             double dl = (same && gi + (same - 1) == gj) ? 1.0 : 0.0;   // same = 1 + row offset of x1 within x2
             v = scale * ((1.0 - nt) * c0 + nt * dl) * cs[j];
         }
@@ -1731,11 +1756,163 @@ __global__ __launch_bounds__(256) void grad_kernel(const T* __restrict__ V, size
     __syncthreads();
     if (tid < d + 2) {
         const int e = tid < d ? tid : (DD + tid - d);
-        double* dst = part + ((size_t)k * ntile + blockIdx.x) * (DMAX + 2);
+        double* dst = part + ((size_t)k * ntile + blockIdx.x) * (DMAX + 2);       // (stride of the narrow kernels: d <= 32)
         dst[tid] = (red[0][e] + red[1][e]) + (red[2][e] + red[3][e]);
     }
     if constexpr (CZ) {
         // rows: the 32 lanes of a half wave share the thread's 8 rows (butterfly); columns: the 8 row groups through LDS
+        __shared__ double c2s[8][TS];
+#pragma unroll
+        for (int m = 0; m < 8; ++m) {
+            double v = cz1[m];
+            for (int off = 16; off > 0; off >>= 1) v += __shfl_xor(v, off);
+            cz1[m] = v;
+        }
+        c2s[tid >> 5][j0] = cz2[0];
+        c2s[tid >> 5][j0 + 1] = cz2[1];
+        __syncthreads();
+        double* dst = cpart + ((size_t)k * ntile + blockIdx.x) * 2 * TS;
+        if ((tid & 31) == 0) {
+#pragma unroll
+            for (int m = 0; m < 8; ++m) dst[(tid >> 5) * 8 + m] = cz1[m];
+        }
+        if (tid < TS)
+            dst[TS + tid] = ((c2s[0][tid] + c2s[1][tid]) + (c2s[2][tid] + c2s[3][tid])) +
+                            ((c2s[4][tid] + c2s[5][tid]) + (c2s[6][tid] + c2s[7][tid]));
+    }
+}
+
+// The same contraction for d > 32 (the reference's kernel loops over any number of input dimensions, covmat.py:35-42;
+// its examples stop at 10): the dimensions are staged in LDS 32 at a time.  A first sweep over the chunks gives every
+// element its total product and exponent; then one sweep per chunk with the dimension as the OUTER loop,
+//   sum_ij G_ij e^{-sum S} S_j^2 prod_{i != j} (1 + S_i)  =  sum_ij ge_ij S_j^2 (prod_ij / (1 + S_j)),
+// one accumulator at a time (per-thread accumulators for all d dimensions would not fit the register file; the division
+// replaces the prefix/suffix products of the narrow kernels).  Per-tile partial sums have stride d + 2.
+template <typename T>
+__global__ __launch_bounds__(256) void grad_kernel_wide(const T* __restrict__ V, size_t mat, int n, int npad, int d, int p,
+                                                        const T* __restrict__ x, const T* __restrict__ sr,
+                                                        const T* __restrict__ z, const double* __restrict__ theta,
+                                                        double* __restrict__ part, int ntile, const T* __restrict__ Y,
+                                                        const T* __restrict__ bvec, double* __restrict__ out,
+                                                        double* __restrict__ cpart) {
+    constexpr bool CZ = sizeof(T) == 4;
+    if ((int)blockIdx.x >= ntile) {
+        gsig_body<T>(blockIdx.x - ntile, blockIdx.y, n, npad, d, p, Y, bvec, z, out);
+        return;
+    }
+    __shared__ double xr[TS][DMAX + 1];
+    __shared__ double xc[TS][DMAX + 1];
+    __shared__ double zr[TS], zc[TS], srr[TS], src[TS];
+    __shared__ double red[4][DWIDE + 2];
+    const int k = blockIdx.y;
+    int r, c;
+    tri_decode(blockIdx.x, r, c);
+    const double* th = th_row(theta, d, p, k);
+    const double D = th[d + 2];
+    const double scale_c = th[d], nt_c = th[d + 1] / (1.0 + th[d + 1]);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid < TS) {
+        int gi = r * TS + tid, gj = c * TS + tid;
+        zr[tid] = (double)z[(size_t)k * npad + gi];
+        zc[tid] = (double)z[(size_t)k * npad + gj];
+        srr[tid] = (sr && gi < n) ? (double)sr[gi] : 1.0;
+        src[tid] = (sr && gj < n) ? (double)sr[gj] : 1.0;
+    }
+    const T* Vk = V + (size_t)k * mat;
+    const int j0 = (tid & 31) * 2;
+    typedef T pair_t __attribute__((ext_vector_type(2)));
+    pair_t avs[8];
+#pragma unroll
+    for (int m = 0; m < 8; ++m)
+        avs[m] = *(const pair_t*)(Vk + (size_t)(r * TS + (tid >> 5) * 8 + m) * npad + c * TS + j0);
+    auto stage = [&](int d0) {       // scaled inputs of the dimensions d0 .. d0 + 31 (zero beyond d)
+        __syncthreads();
+        for (int e = tid; e < TS * DMAX; e += 256) {
+            int i = e / DMAX, jj = e - i * DMAX;
+            int gi = r * TS + i, gj = c * TS + i;
+            xr[i][jj] = (d0 + jj < d && gi < n) ? (double)x[(size_t)gi * d + d0 + jj] / th[d0 + jj] : 0.0;
+            xc[i][jj] = (d0 + jj < d && gj < n) ? (double)x[(size_t)gj * d + d0 + jj] / th[d0 + jj] : 0.0;
+        }
+        __syncthreads();
+    };
+    double prodT[16], geT[16];          // element e = 2 m + h: total product, then G e^{-sum S}
+#pragma unroll
+    for (int e = 0; e < 16; ++e) { prodT[e] = 1.0; geT[e] = 0.0; }
+    for (int d0 = 0; d0 < d; d0 += DMAX) {
+        stage(d0);
+#pragma unroll
+        for (int m = 0; m < 8; ++m)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int i = (tid >> 5) * 8 + m, j = j0 + h;
+                double pr = prodT[2 * m + h], ss = geT[2 * m + h];
+                for (int jj = 0; jj < DMAX; ++jj) {
+                    const double s = fabs(xr[i][jj] - xc[j][jj]);
+                    pr = fma(pr, s, pr);
+                    ss -= s;
+                }
+                prodT[2 * m + h] = pr;
+                geT[2 * m + h] = ss;
+            }
+    }
+    double a_scale = 0.0, a_nug = 0.0;
+    double cz1[CZ ? 8 : 1], cz2[CZ ? 2 : 1];
+    if constexpr (CZ) {
+#pragma unroll
+        for (int m = 0; m < 8; ++m) cz1[m] = 0.0;
+        cz2[0] = cz2[1] = 0.0;
+    }
+#pragma unroll
+    for (int m = 0; m < 8; ++m)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int i = (tid >> 5) * 8 + m, j = j0 + h;
+            const int gi = r * TS + i, gj = c * TS + j;
+            double ge = 0.0;
+            if (gi < n && gj < n && gj <= gi) {
+                const double wgt = gi == gj ? 1.0 : 2.0;
+                const double G = wgt * srr[i] * src[j] * (0.5 * D * (double)avs[m][h] - 0.5 * zr[i] * zc[j]);
+                const double ex = exp_nonpos(geT[2 * m + h]);
+                ge = G * ex;
+                a_scale = fma(ge, prodT[2 * m + h], a_scale);
+                if (gi == gj) a_nug += G;
+                if constexpr (CZ) {
+                    const double cs = srr[i] * src[j] * scale_c * ((1.0 - nt_c) * (ex * prodT[2 * m + h]) + (gi == gj ? nt_c : 0.0));
+                    cz1[m] = fma(cs, zc[j], cz1[m]);
+                    if (gi != gj) cz2[h] = fma(cs, zr[i], cz2[h]);
+                }
+            }
+            geT[2 * m + h] = ge;
+        }
+    auto wave_sum = [&](double v) {
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+        return v;
+    };
+    for (int d0 = 0; d0 < d; d0 += DMAX) {
+        stage(d0);
+        const int dc = d - d0 < DMAX ? d - d0 : DMAX;
+        for (int jj = 0; jj < dc; ++jj) {
+            double a = 0.0;
+#pragma unroll
+            for (int m = 0; m < 8; ++m)
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const double s = fabs(xr[(tid >> 5) * 8 + m][jj] - xc[j0 + h][jj]);
+                    a = fma(geT[2 * m + h] * (s * s), prodT[2 * m + h] / (1.0 + s), a);
+                }
+            a = wave_sum(a);
+            if (lane == 0) red[wave][d0 + jj] = a;
+        }
+    }
+    a_scale = wave_sum(a_scale);
+    a_nug = wave_sum(a_nug);
+    if (lane == 0) { red[wave][d] = a_scale; red[wave][d + 1] = a_nug; }
+    __syncthreads();
+    if (tid < d + 2) {
+        double* dst = part + ((size_t)k * ntile + blockIdx.x) * (d + 2);
+        dst[tid] = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
+    }
+    if constexpr (CZ) {
         __shared__ double c2s[8][TS];
 #pragma unroll
         for (int m = 0; m < 8; ++m) {
@@ -1796,7 +1973,8 @@ __global__ __launch_bounds__(256) void finalize_kernel(int n, int npad, int d, i
                                                        const double* __restrict__ cvec /*float32: (C o s s^T) z, else null*/) {
     __shared__ double sh[4];
     __shared__ double grp[256];
-    __shared__ double sums[DMAX + 2];
+    __shared__ double sums[DWIDE + 2];
+    const int pstride = (d > DMAX ? d : DMAX) + 2;       // doubles per tile in `part` (grad_kernel / grad_kernel_wide)
     const int k = blockIdx.x;
     const int tid = threadIdx.x;
     const double* th = th_row(theta, d, p, k);
@@ -1811,15 +1989,15 @@ __global__ __launch_bounds__(256) void finalize_kernel(int n, int npad, int d, i
     if (g < ng) {
         // four independent chains (the loads of one chain would otherwise wait for each other), combined in a fixed order
         double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
-        const double* pk = part + (size_t)k * ntile * (DMAX + 2) + e;
+        const double* pk = part + (size_t)k * ntile * pstride + e;
         int t = g;
         for (; t + 3 * ng < ntile; t += 4 * ng) {
-            a0 += pk[(size_t)t * (DMAX + 2)];
-            a1 += pk[(size_t)(t + ng) * (DMAX + 2)];
-            a2 += pk[(size_t)(t + 2 * ng) * (DMAX + 2)];
-            a3 += pk[(size_t)(t + 3 * ng) * (DMAX + 2)];
+            a0 += pk[(size_t)t * pstride];
+            a1 += pk[(size_t)(t + ng) * pstride];
+            a2 += pk[(size_t)(t + 2 * ng) * pstride];
+            a3 += pk[(size_t)(t + 3 * ng) * pstride];
         }
-        for (; t < ntile; t += ng) a0 += pk[(size_t)t * (DMAX + 2)];
+        for (; t < ntile; t += ng) a0 += pk[(size_t)t * pstride];
         acc = (a0 + a1) + (a2 + a3);
     }
     grp[tid] = acc;
@@ -2202,7 +2380,12 @@ int do_nll_grad(hipStream_t st, const Ws& w, const lcgp_sched& sc, const void* x
     else if (w.d <= 6) launch_grad<T, 6>(st, w, x, sr, theta, Y, out);
     else if (w.d <= 10) launch_grad<T, 10>(st, w, x, sr, theta, Y, out);
     else if (w.d <= 16) launch_grad<T, 16>(st, w, x, sr, theta, Y, out);
-    else launch_grad<T, DMAX>(st, w, x, sr, theta, Y, out);
+    else if (w.d <= DMAX) launch_grad<T, DMAX>(st, w, x, sr, theta, Y, out);
+    else
+        hipLaunchKernelGGL((grad_kernel_wide<T>), dim3(w.ntile_lower + (sizeof(T) == 4 ? 0 : w.p), w.q), dim3(256), 0, st,
+                           (const T*)(w.base + w.off_V), w.mat, w.n, w.npad, w.d, w.p, (const T*)x, (const T*)sr,
+                           (const T*)(w.base + w.off_z), theta, (double*)(w.base + w.off_part), w.ntile_lower, (const T*)Y,
+                           (const T*)(w.base + w.off_b), out, (double*)(w.base + w.off_cpart));
     CHECK_LAUNCH("grad_kernel");
     const double* cvec = nullptr;
     if constexpr (sizeof(T) == 4) {
@@ -2268,7 +2451,7 @@ __global__ __launch_bounds__(256) void pack_partial_kernel(int d, int p, int q_l
 int check_common(int dtype, int n, int d, int p, int q) {
     if (dtype != LCGP_F64 && dtype != LCGP_F32) return bad("dtype must be 0 (f64) or 1 (f32)");
     if (n < 1) return bad("n < 1");
-    if (d < 1 || d > DMAX) return bad("d must be in [1, 32]");
+    if (d < 1 || d > DWIDE) return bad("d must be in [1, 126]");
     if (p < 1) return bad("p < 1");
     if (q < 1 || q > 65535) return bad("q_local must be in [1, 65535]");
     return 0;
@@ -2372,7 +2555,7 @@ int lcgp_matern32(void* stream, int dtype, int n1, int n2, int d, const void* x1
                   double scale, double nug, int same, void* out) {
     if (dtype != LCGP_F64 && dtype != LCGP_F32) return bad("dtype must be 0 (f64) or 1 (f32)");
     if (n1 < 1 || n2 < 1) return bad("n1/n2 < 1");
-    if (d < 1 || d > DMAX) return bad("d must be in [1, 32]");
+    if (d < 1 || d > DWIDE) return bad("d must be in [1, 126]");
     if (!x1 || !x2 || !ell || !out) return bad("NULL pointer");
     ThetaArg th;
     memset(&th, 0, sizeof(th));
@@ -2491,7 +2674,7 @@ int lcgp_nll_grad(void* stream, int dtype, int n, int d, int p, int q_local, con
 
 int lcgp_pack_partial(void* stream, int d, int p, int q_local, int q_total, const int* comp, const double* theta,
                       const double* out, const double* guard, double* vec) {
-    if (d < 1 || d > DMAX || p < 1) return bad("d must be in [1, 32], p >= 1");
+    if (d < 1 || d > DWIDE || p < 1) return bad("d must be in [1, 126], p >= 1");
     if (q_local < 0 || q_total < 1 || q_local > q_total) return bad("need 0 <= q_local <= q_total, q_total >= 1");
     if (!vec || (q_local > 0 && (!comp || !theta || !out))) return bad("NULL pointer");
     hipLaunchKernelGGL(pack_partial_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, d, p, q_local, q_total, comp, theta,

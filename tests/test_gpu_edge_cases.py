@@ -43,11 +43,44 @@ def test_wide_input_dimensions(seed, d):
     np.testing.assert_allclose(m.predict(x[:5])[0].numpy(), o.predict(x[:5])[0], rtol=1e-7, atol=1e-9)
 
 
+@pytest.mark.parametrize('seed,n,d,kw', [(319, 90, 33, {}), (3191, 150, 40, {}), (3192, 70, 64, {}), (3193, 200, 75, dict(q=1)),
+                                         (3194, 80, 126, {})])
+def test_more_than_32_input_dimensions(seed, n, d, kw):
+    """The reference's kernel loops over any number of input dimensions (covmat.py:35-42).  Beyond 32 the kernels stage the
+    dimensions 32 at a time (kernel build, cross covariance, grad_kernel_wide): NLL, every gradient entry (d lengthscales
+    per component) and predictions against the oracle, and Matern32 itself against the restatement."""
+    x, y = synth.make_full(seed, n, d, 3, 2)
+    q = kw.get('q', 2)
+    m = LCGP(y=y, x=x, q=q)
+    o = orc.OracleLCGP(y=y, x=x, q=q)
+    for u in synth.param_points(seed, o.get_unconstrained())[:2]:
+        _same(m, o, u)
+    for a, b in zip(m.predict(x[:7] * 0.98 + 0.01), o.predict(x[:7] * 0.98 + 0.01)):
+        np.testing.assert_allclose(a.numpy(), b, rtol=1e-7, atol=1e-9)
+    from lcgp_amd import Matern32
+    ell = np.exp(np.random.default_rng(seed).uniform(0.5, 2.0, d))
+    got = Matern32(x[:70], x[:50], ell, 1.7, 0.01).numpy()
+    want = orc.matern32(x[:70], x[:50], ell, 1.7, 0.01)
+    np.testing.assert_allclose(got, want, rtol=1e-13, atol=1e-300)
+
+
 def test_refusal_above_the_maximum_input_dimension():
-    x33, y33 = synth.make_full(319, 40, 33, 2, 2)
-    m33 = LCGP(y=y33, x=x33, q=2)
+    x127, y127 = synth.make_full(319, 40, 127, 2, 2)
+    m127 = LCGP(y=y127, x=x127, q=2)
     with pytest.raises(RuntimeError, match='d must be'):
-        m33.loss()
+        m127.loss()
+
+
+def test_float32_with_more_than_32_input_dimensions():
+    """the float32 variant of the wide kernels (incl. the cancellation-free quadratic form) against this build's float64"""
+    x, y = synth.make_full(3195, 300, 45, 4, 2)
+    m64 = LCGP(y=y, x=x, q=2)
+    m32 = LCGP(y=y, x=x, q=2, dtype='float32')
+    u = synth.param_points(3195, m64._get_flat())[1]
+    v64, g64 = m64.loss_and_grad(u)
+    v32, g32 = m32.loss_and_grad(u)
+    assert abs(v32 - v64) <= 1e-5 * abs(v64)
+    assert np.max(np.abs(g32 - g64)) <= 1e-3 * np.max(np.abs(g64))
 
 
 def test_duplicated_inputs_in_full_mode():

@@ -303,7 +303,7 @@ def test_c_abi_library_exports_every_declared_symbol():
     nbytes = C.c_size_t(0)
     assert lib.lcgp_workspace_bytes(0, 4096, 6, 64, 8, C.byref(nbytes)) == 0
     assert nbytes.value >= 3 * 8 * 4096 * 4096 * 8
-    assert lib.lcgp_workspace_bytes(0, 4096, 99, 64, 8, C.byref(nbytes)) < 0      # d > 32 refused
+    assert lib.lcgp_workspace_bytes(0, 4096, 127, 64, 8, C.byref(nbytes)) < 0     # d > 126 refused
     assert b'd must be' in lib.lcgp_last_error()
     assert lib.lcgp_partial_width(6, 64, 8) == 3 + 8 * 6 + 2 * 8 + 64      # ... + the lock-step guard word
     sc = _hip.default_sched()                   # schedule parameters travel per call: the library has no setters
