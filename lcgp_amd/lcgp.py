@@ -713,12 +713,18 @@ class LCGP:
                 return None
             ainv = self._fetch_all(lambda e, i: e.fetch_matrix(2, i), n * n).reshape(int(self.q), n, n)
             return _t(D[:, None, None] * ainv * sr[None, :, None] * sr[None, None, :])
-        if name == 'Ths':         # Th_k Th_k^T = D_k A_k^-1 (lcgp.py:709-715); returned as the Cholesky-type factor
+        if name == 'Ths':         # the reference's matrix (lcgp.py:709-715): U diag(sqrt(D / (1 + D w))) U^T, i.e. the SYMMETRIC
+            # square root of D_k A_k^-1 (unique: symmetric positive definite).  predict() never needs it (it works from
+            # L^-1 on the device); this view exists for callers of the reference that read the attribute, and pays an
+            # eigendecomposition of A^-1 per component on the host when -- and only when -- it is read.
             if self.submethod != 'full':
                 return None
-            w = self._fetch_all(lambda e, i: e.fetch_matrix(1, i), n * n).reshape(int(self.q), n, n)
-            w = np.tril(w)
-            return _t(np.sqrt(D)[:, None, None] * np.transpose(w, (0, 2, 1)))
+            ainv = self._fetch_all(lambda e, i: e.fetch_matrix(2, i), n * n).reshape(int(self.q), n, n)
+            out = np.empty_like(ainv)
+            for k in range(int(self.q)):
+                lam, vec = np.linalg.eigh(0.5 * (ainv[k] + ainv[k].T))
+                out[k] = (vec * np.sqrt(D[k] * np.maximum(lam, 0.0))[None, :]) @ vec.T
+            return _t(out)
         raise AttributeError(name)
 
     def _cache_set(self, name, value):

@@ -219,6 +219,9 @@ def test_predict_and_caches_equal_oracle_through_stand_in(mode):
         np.testing.assert_allclose(got[3].numpy(), want[3], rtol=1e-8, atol=1e-10)
         diag = np.diagonal(got[3].numpy(), axis1=1, axis2=2).T
         np.testing.assert_allclose(diag, got[1].numpy(), rtol=1e-5, atol=1e-6)
+        aux = o._aux_full()          # the caches the reference keeps as attributes (lcgp.py:708-715), its own matrices
+        np.testing.assert_allclose(m.CinvMs.numpy(), aux['CinvMs'], rtol=1e-7, atol=1e-9)
+        np.testing.assert_allclose(m.Ths.numpy(), aux['Ths'], rtol=1e-7, atol=1e-9)
     else:
         assert got[3] is None
         aux = o._aux_rep()
