@@ -79,6 +79,9 @@ typedef struct lcgp_sched {
     int progressive_far;    /* with the progressive inverse: 1 = the far columns of a trailing update still ride on the next
                                panel's chain launches, 0 = every trailing update is one wide launch (the chain launches
                                carry the jobs of the inverse only) */
+    int progressive_lauum;  /* with the progressive inverse: A^-1 = W^T W is accumulated behind the chain as well when the matrix
+                               has at most this many 64-blocks per side (48); beyond, only L^-1 is, and A^-1 takes the one
+                               launch of lcgp_lauum after the factorisation (0 = always that) */
 } lcgp_sched;
 int lcgp_sched_default(lcgp_sched* sched /*host out*/);
 

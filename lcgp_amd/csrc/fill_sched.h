@@ -269,6 +269,8 @@ struct PlanParams {
     int syrk_small_tiles, fill_leaf, fill_step, leaf_in_wide;     // lcgp_sched fields of the same names
     bool progressive;        // queue the jobs of the progressive inverse
     bool far_rides;          // the far columns of a trailing update ride on the next panel's chain (else: one wide launch)
+    bool with_dupd = true;   // progressive: A^-1 = W^T W is accumulated behind the chain too (else only L^-1 is; the caller
+                             // then forms A^-1 in one launch after the factorisation)
 };
 
 enum LaunchKind {
@@ -432,7 +434,7 @@ class Planner {
             jb.wave = last_cupd;
             last_cupd = fq.add(jb);
         }
-        {
+        if (pp.with_dupd) {
             QJob jb;
             jb.j.type = FILL_DUPD;
             jb.j.R0 = 0; jb.j.R1 = (pe + 1) / 2; jb.j.j0 = 0; jb.j.j1 = pe; jb.j.kb0 = J; jb.j.kb1 = pe;

@@ -2133,13 +2133,16 @@ inline lcgp_sched default_sched() {
     s.progressive_tiles = 600;     // L^-1 and A^-1 formed behind the chain up to this many 128x128 lower tiles x components
                                    // (n = 4096: one component per rank; measured 2.72 -> 2.55 ms there, slower from two on)
     s.progressive_far = 1;         // ... with the far columns of the trailing updates still riding on the chain
+    s.progressive_lauum = 48;      // ... and A^-1 = W^T W accumulated behind the chain as well up to this many 64-blocks per side
+                                   // (n = 2048: 1.12 -> 0.98 ms; at n = 4096 its tail is one ragged launch of long K loops
+                                   // that loses to the one-launch W^T W: 2.54 vs 2.43 ms)
     return s;
 }
 
 inline int check_sched(const lcgp_sched& s) {
     if (s.outer_blocks < 0 || s.outer_blocks > 64) return bad("sched.outer_blocks must be in [0, 64]");
     if (s.syrk_small_tiles < 0 || s.trtri_small_tiles < 0 || s.lauum_small_tiles < 0 || s.trtri_level_small < 0 ||
-        s.fill_leaf < 0 || s.fill_step < 0 || s.leaf_in_wide < 0 || s.progressive_tiles < 0)
+        s.fill_leaf < 0 || s.fill_step < 0 || s.leaf_in_wide < 0 || s.progressive_tiles < 0 || s.progressive_lauum < 0)
         return bad("sched fields must be >= 0");
     return 0;
 }
@@ -2211,7 +2214,7 @@ inline bool use_progressive(const Ws& w, const lcgp_sched& sc, int ob) {
 // only, also replayed on the CPU by tests/native/test_fill_sched.cpp) and then enqueued here launch by launch.
 template <typename T>
 int do_potrf(hipStream_t st, const Ws& w, const lcgp_sched& sc, bool stats_zeroed = false, bool with_inverse = false,
-             bool* inverse_done = nullptr) {
+             int* inverse_done = nullptr /* 0 = nothing, 1 = L^-1, 2 = L^-1 and A^-1 */) {
     T* M = (T*)(w.base + w.off_M);
     T* W = (T*)(w.base + w.off_W);
     double* logdet = (double*)(w.base + w.off_logdet);
@@ -2227,7 +2230,8 @@ int do_potrf(hipStream_t st, const Ws& w, const lcgp_sched& sc, bool stats_zeroe
     pp.leaf_in_wide = sc.leaf_in_wide;
     pp.progressive = with_inverse && use_progressive(w, sc, pp.ob);
     pp.far_rides = !(pp.progressive && sc.progressive_far == 0);
-    if (inverse_done) *inverse_done = pp.progressive;
+    pp.with_dupd = w.nb <= sc.progressive_lauum;
+    if (inverse_done) *inverse_done = pp.progressive ? (pp.with_dupd ? 2 : 1) : 0;
     lcgp_fill::Planner plan(pp);
     plan.run();
     if (plan.failed) return bad("internal: the filler queue did not drain");
@@ -2355,14 +2359,13 @@ int do_nll_grad(hipStream_t st, const Ws& w, const lcgp_sched& sc, const void* x
     if (rc) return rc;
     T* b = (T*)(w.base + w.off_b);
     T* z = (T*)(w.base + w.off_z);
-    bool inverse_done = false;     // the progressive inverse has left L^-1 and A^-1 behind the factorisation
+    int inverse_done = 0;          // what the progressive inverse has left behind the factorisation: 1 = L^-1, 2 = and A^-1
     rc = do_potrf<T>(st, w, sc, true, true, &inverse_done);
     if (rc) return rc;
     bool z_partials = false;       // z = A^-1 b: per-tile partials from the 128-tile LAUUM's epilogue, or a pass of its own
-    if (!inverse_done) {
-        rc = do_potri<T>(st, w, sc, &z_partials);
-        if (rc) return rc;
-    }
+    if (inverse_done == 0) rc = do_potri<T>(st, w, sc, &z_partials);
+    else if (inverse_done == 1) rc = do_lauum<T>(st, w, sc, &z_partials);
+    if (rc) return rc;
     if (z_partials) {
         const int nb2 = w.nb / 2;
         hipLaunchKernelGGL((symv_reduce_kernel<T, 128>), dim3(nb2, w.q), dim3(256), 0, st,

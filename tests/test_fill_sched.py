@@ -23,8 +23,9 @@ def dump_plan(tmp_path_factory):
     subprocess.run(['g++', '-std=c++17', '-O1', '-I', os.path.join(ROOT, 'lcgp_amd', 'csrc'), '-o', exe,
                     os.path.join(ROOT, 'tests', 'native', 'dump_plan.cpp')], check=True)
 
-    def run(nb, q, ob, syrk_small=2000, fill_leaf=248, fill_step=248, leaf_in_wide=1024, progressive=1):
-        out = subprocess.run([exe] + [str(v) for v in (nb, q, ob, syrk_small, fill_leaf, fill_step, leaf_in_wide, progressive)],
+    def run(nb, q, ob, syrk_small=2000, fill_leaf=248, fill_step=248, leaf_in_wide=1024, progressive=1, far_rides=1, with_dupd=1):
+        out = subprocess.run([exe] + [str(v) for v in (nb, q, ob, syrk_small, fill_leaf, fill_step, leaf_in_wide, progressive,
+                                                       far_rides, with_dupd)],
                              check=True, capture_output=True, text=True).stdout
         assert 'FAILED' not in out
         launches = []
@@ -215,7 +216,7 @@ class Replay:
             self.run_jobs(l)
             self.end_launch()
 
-    def check(self, inverse):
+    def check(self, inverse, ainv=True):
         L = np.linalg.cholesky(self.A)
         n = L.shape[0]
         low = np.tril(np.ones((n, n), bool))
@@ -224,6 +225,8 @@ class Replay:
             Wt = np.linalg.inv(L)
             Ai = np.linalg.inv(self.A)
             assert np.allclose(self.W[low], Wt[low], rtol=0, atol=1e-9), 'L^-1'
+            if not ainv:
+                return
             assert np.allclose(self.V[low], Ai[low], rtol=0, atol=1e-9), 'A^-1'
             for b in range(self.nb):     # whole diagonal tiles of A^-1 (the symv pass reads them whole)
                 s = slice(b * TS, (b + 1) * TS)
@@ -249,6 +252,7 @@ CASES = [
     (32, 1, 4, dict(fill_leaf=40, fill_step=24)),
     (32, 2, 4, dict(leaf_in_wide=0)),
     (32, 1, 4, dict(syrk_small=0)),               # wide updates on 128-tiles
+    (32, 2, 4, dict(far_rides=0)),                # every trailing update is one wide launch
 ]
 
 
@@ -258,6 +262,17 @@ def test_plan_with_progressive_inverse_replays_to_the_inverse(dump_plan, nb, q, 
     r = Replay(nb, q, seed=nb + q)
     r.run(launches)
     r.check(inverse=True)
+
+
+@pytest.mark.parametrize('nb,q,ob,kw', [(64, 1, 4, {}), (64, 2, 4, dict(far_rides=0)), (18, 1, 4, {}), (24, 2, 8, {}), (6, 1, 4, {}),
+                                        (32, 1, 4, dict(fill_leaf=40, fill_step=24))])
+def test_plan_with_the_triangular_inverse_only(dump_plan, nb, q, ob, kw):
+    """large matrices: only L^-1 is formed behind the chain (A^-1 = W^T W takes its one launch afterwards)"""
+    launches = dump_plan(nb, q, ob, progressive=1, with_dupd=0, **kw)
+    assert not any(jb['type'] == 4 for l in launches for jb in l['jobs'])
+    r = Replay(nb, q, seed=3 * nb + q)
+    r.run(launches)
+    r.check(inverse=True, ainv=False)
 
 
 @pytest.mark.parametrize('nb,q,ob,kw', CASES[:8] + [(14, 2, 6, {}), (16, 1, 3, {})])

@@ -202,7 +202,8 @@ def test_schedule_parameters_do_not_change_results():
                        dict(progressive_tiles=0), dict(progressive_tiles=1 << 30), dict(progressive_tiles=1 << 30, outer_blocks=2),
                        dict(progressive_tiles=1 << 30, outer_blocks=8), dict(progressive_tiles=1 << 30, fill_leaf=0, fill_step=0),
                        dict(progressive_tiles=1 << 30, fill_leaf=12, fill_step=20), dict(progressive_tiles=1 << 30, progressive_far=0),
-                       dict(progressive_tiles=1 << 30, leaf_in_wide=0), dict(progressive_tiles=1 << 30, outer_blocks=3)):
+                       dict(progressive_tiles=1 << 30, leaf_in_wide=0), dict(progressive_tiles=1 << 30, outer_blocks=3),
+                       dict(progressive_tiles=1 << 30, progressive_lauum=0), dict(progressive_tiles=1 << 30, progressive_lauum=0, outer_blocks=2)):
             eng.sched = _sched(**fields)
             v, g = m.loss_and_grad(u)
             assert abs(v - ref_v) <= 1e-11 * abs(ref_v), fields
@@ -264,7 +265,8 @@ def test_progressive_inverse_with_jobs_split_over_launches():
         ref_p = [t.numpy() for t in m.predict(x[:50] + 0.003)]
         ref_w, ref_a, ref_z = np.tril(eng.fetch_matrix(1, 5)), np.tril(eng.fetch_matrix(2, 5)), eng.fetch_vector(1, 5)
         for fields in (dict(progressive_tiles=1 << 30), dict(progressive_tiles=1 << 30, fill_leaf=30, fill_step=18),
-                       dict(progressive_tiles=1 << 30, fill_leaf=6, fill_step=6), dict(progressive_tiles=1 << 30, progressive_far=0)):
+                       dict(progressive_tiles=1 << 30, fill_leaf=6, fill_step=6), dict(progressive_tiles=1 << 30, progressive_far=0),
+                       dict(progressive_tiles=1 << 30, progressive_lauum=0), dict(progressive_tiles=1 << 30, progressive_lauum=0, fill_leaf=30, fill_step=18)):
             eng.sched = _sched(**fields)
             v, g = m.loss_and_grad(u)
             assert abs(v - ref_v) <= 1e-11 * abs(ref_v), fields

@@ -18,6 +18,7 @@ def run(tag, x, y, q, submethod='full', dtype='float64', seed=1, ob=0):
         m = LCGP(y=y, x=x, q=q, submethod=submethod, dtype=dtype)
         sc = _hip.default_sched()
         sc.progressive_tiles = prog
+        sc.progressive_lauum = 1 << 30
         sc.outer_blocks = ob
         m._get_engine().sched = sc
         u = synth.param_points(seed, m._get_flat())[1]
