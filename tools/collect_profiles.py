@@ -40,13 +40,18 @@ def main():
     for a, b in (('bench.json', 'bench.json'), ('bench_cfg2.json', 'bench_cfg2.json'), ('bench_cfg4.json', 'bench_cfg4.json'),
                  ('bench_cfg5.json', 'bench_cfg5.json'), ('bench_q4.json', 'bench_q4.json'), ('bench_q2.json', 'bench_q2.json'),
                  ('bench_q1.json', 'bench_q1.json'), ('bench_gloo2.json', 'bench_gloo2_one_gpu.json'),
-                 ('host_overhead.txt', 'host_overhead.txt')):
+                 ('host_overhead.txt', 'host_overhead.txt'), ('timeline_q1_progressive.txt', 'timeline_q1_progressive.txt'),
+                 ('timeline_q1_classic.txt', 'timeline_q1_classic.txt'), ('fit_wallclock.txt', 'fit_wallclock.txt')):
+        if not os.path.exists(os.path.join(src, a)):
+            continue
         shutil.copy(os.path.join(src, a), os.path.join(dst, '%s_%s' % (pre, b)))
     shutil.copy(glob.glob(src + '/stats/*/*kernel_stats.csv')[0], os.path.join(dst, pre + '_bench_kernel_stats.csv'))
     for d, name in (('pmc_fetch', 'pmc_fetch_size'), ('pmc_write', 'pmc_write_size'), ('pmc_valu', 'pmc_valu_cfg3'),
-                    ('pmc_valu_cfg4', 'pmc_valu_cfg4'), ('pmc_mfma', 'pmc_mfma')):
+                    ('pmc_valu_cfg4', 'pmc_valu_cfg4'), ('pmc_mfma', 'pmc_mfma'), ('pmc_mfma_q1', 'pmc_mfma_q1')):
+        if not os.path.isdir(os.path.join(src, d)):
+            continue
         open(os.path.join(dst, '%s_%s.txt' % (pre, name)), 'w').write(summary(os.path.join(src, d)))
-    bench = json.loads(open(os.path.join(src, 'bench.json')).read().strip().splitlines()[-1])
+    bench = json.loads([ln for ln in open(os.path.join(src, 'bench.json')).read().strip().splitlines() if ln.startswith('{')][-1])
     lib_hash = subprocess.check_output([sys.executable, '-c', 'import sys; sys.path.insert(0, %r); from lcgp_amd import _hip; '
                                         'print(_hip.source_hash())' % ROOT]).decode().strip()
     fetch = per_kernel(os.path.join(src, 'pmc_fetch'), 'FETCH_SIZE')

@@ -18,4 +18,5 @@ out = m.predict(x0)
 t4 = time.perf_counter()
 print('config %d: construct %.2f s | fit %.2f s (%d iterations, %d evaluations, %.1f ms/eval, loss %.4f -> %.4f, %s) | '
       'predict(2000) %.3f s' % (cfgid, t1 - t0, t3 - t2, res.nit, res.nfev, 1e3 * (t3 - t2) / res.nfev, l0, res.fun,
-                                res.message if isinstance(res.message, str) else res.message.decode(), t4 - t3))
+                                res.message if isinstance(res.message, str) else res.message.decode(), t4 - t3)
+      + (' | float32: %d evaluations fell back to float64' % m.float32_fallbacks if cfg['dtype'] != 'f64' else ''))

@@ -4,7 +4,7 @@
 # rocprofv3 passes: --kernel-trace --stats on its own; every --pmc pass on its own with --kernel-trace only
 # (never together with the hip/hsa/memory trace domains); the program itself follows `--`.
 set -u
-TAG=${1:-r02}
+TAG=${1:-r03}
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$ROOT/gpurun_out/$TAG
 mkdir -p "$OUT"
@@ -31,6 +31,15 @@ step "PMC: WRITE_SIZE"
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 $ROOT/tools/run_evals.py 3 0 3 > $OUT/pmc_write.log 2>&1 || exit 1
 step "PMC: MFMA busy"
 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F64 GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_mfma -- python3 $ROOT/tools/run_evals.py 3 0 3 > $OUT/pmc_mfma.log 2>&1 || exit 1
+step "PMC: MFMA busy, one component (the 8-GPU share: inverse formed behind the chain)"
+rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F64 GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_mfma_q1 -- python3 $ROOT/tools/run_evals.py 3 1 3 > $OUT/pmc_mfma_q1.log 2>&1 || exit 1
+step "kernel trace, one component, progressive (default) and classic schedule"
+rocprofv3 --kernel-trace --output-format csv -d $OUT/trace_q1 -- python3 $ROOT/tools/run_evals.py 3 1 4 > $OUT/trace_q1.log 2>&1 || exit 1
+rocprofv3 --kernel-trace --output-format csv -d $OUT/trace_q1_classic -- python3 $ROOT/tools/run_evals.py 3 1 4 progressive_tiles=0 > $OUT/trace_q1_classic.log 2>&1 || exit 1
+python3 $ROOT/tools/trace_view.py $(find $OUT/trace_q1 -name '*kernel_trace.csv' | head -1) > $OUT/timeline_q1_progressive.txt
+python3 $ROOT/tools/trace_view.py $(find $OUT/trace_q1_classic -name '*kernel_trace.csv' | head -1) > $OUT/timeline_q1_classic.txt
+step "fit() wall-clock of every configuration"
+for c in 3 2 5 4; do python3 $ROOT/tools/fit_wallclock.py $c >> $OUT/fit_wallclock.txt 2>&1 || true; done
 step "two ranks on this one GPU over gloo (rehearsal of the N > 1 launch line; RCCL needs one GPU per rank)"
 cd $ROOT && python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 2 --steps 6 --warmup 2 --backend gloo --no-cpu-baseline > $OUT/bench_gloo2.json 2> $OUT/bench_gloo2.err || exit 1
 step done
