@@ -2,7 +2,7 @@
 """LCGP hot-path benchmark: NLL + gradient evaluations per second at BASELINE.json's headline configuration
 (n=4096, d=6, p=64 -> q=8 latent components, fp64), on N GPUs of one node.
 
-    python bench.py --gpus 1 --steps 20 --warmup 3
+    python bench.py --gpus 1 --steps 50 --warmup 3
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
@@ -31,7 +31,7 @@ T_START = time.perf_counter()
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--steps', type=int, default=50)
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--config', type=int, default=3, help='synthetic config id of lcgp_amd/synth.py (3 = headline)')
     ap.add_argument('--n', type=int, default=None, help='override n (debug only; invalidates the headline metric)')
