@@ -55,6 +55,18 @@ def main():
     except RuntimeError as e:
         assert 'lock-step' in str(e)
     m.loss_and_grad(u)
+    # the headline configuration as a 2-GPU job would run it (q_local = 4 per rank: that share's tile-size thresholds)
+    # against the committed golden: NLL and all 128 gradient entries at one point
+    gold = np.load(os.path.join(ROOT, 'tests', 'golden', 'lcgp_golden_large.npz'))
+    x, y, cfg = synth.make_config(3)
+    m = LCGP(y=y, x=x, q=cfg['q'], device="cuda:0")
+    v, g = m.loss_and_grad(gold['cfg3_n4096/u'][1])
+    assert m._engine.q_local == 4 and m._local_ks == list(range(rank, 8, 2))
+    want_v, want_g = gold['cfg3_n4096/nll'][1], gold['cfg3_n4096/grad'][1]
+    assert abs(v - want_v) <= 1e-6 * abs(want_v), (rank, v, want_v)
+    assert np.max(np.abs(g - want_g)) <= 1e-5 * np.max(np.abs(want_g))
+    del m
+    torch.cuda.empty_cache()
     # q < world: rank 1 holds no component, has no engine, and still takes part in every collective
     x, y = synth.make_full(33, 200, 2, 3, 1)
     m = LCGP(y=y, x=x, q=1, device="cuda:0")
