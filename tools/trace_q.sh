@@ -1,5 +1,5 @@
 #!/bin/bash
-# kernel trace of a few evaluations of the headline configuration at q components: bash tools/_trace_q.sh <q> <tag> [sched field=value ...]
+# kernel trace of a few evaluations of the headline configuration at q components: bash tools/trace_q.sh <q> <tag> [sched field=value ...]
 Q=$1; TAG=$2; shift; shift
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/tr_$TAG
