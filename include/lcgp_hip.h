@@ -82,6 +82,11 @@ typedef struct lcgp_sched {
     int progressive_lauum;  /* with the progressive inverse: A^-1 = W^T W is accumulated behind the chain as well when the matrix
                                has at most this many 64-blocks per side (48); beyond, only L^-1 is, and A^-1 takes the one
                                launch of lcgp_lauum after the factorisation (0 = always that) */
+    int dag;                /* with a plan (lcgp_plan_build): 1 = the factorisation runs as ONE persistent launch whose tasks wait
+                               for each other through per-(segment, component) counters in the workspace, 0 = launch by launch */
+    int dag_spin_limit;     /* polls of one wait inside that launch before it gives up: the failure word is set, every later
+                               wait returns at once, the launch drains and every component reports info = -1
+                               (0 = 2,000,000 polls, about two seconds; tests set 1 to see the failure path) */
 } lcgp_sched;
 int lcgp_sched_default(lcgp_sched* sched /*host out*/);
 
@@ -109,7 +114,8 @@ int lcgp_kernel_build(void* stream, int dtype, int n, int d, int p, int q_local,
  * tf.linalg.cholesky (lcgp.py:617) and the log-determinant (lcgp.py:660 / 624).
  * half_logdet (q_local doubles) and info (q_local ints) are written on the device (either may be NULL). */
 int lcgp_potrf_logdet(void* stream, int dtype, int n, int d, int p, int q_local, void* workspace,
-                      double* half_logdet, int* info, const lcgp_sched* sched /*host or NULL*/);
+                      double* half_logdet, int* info, const lcgp_sched* sched /*host or NULL*/,
+                      const void* plan_host /*or NULL*/, const void* plan_dev /*or NULL*/);
 
 /* K4: A_k^-1 (lower tiles) from the factor left by lcgp_potrf_logdet.  Replaces the dense
  * U diag(.) U^T products of lcgp.py:654 / 705-715 and cholesky_solve with identity (lcgp.py:785). */
@@ -140,7 +146,22 @@ int lcgp_fetch_vector(void* stream, int dtype, int n, int d, int p, int q_local,
  *   theta, out : device blocks described at the top (q_local rows each) */
 int lcgp_nll_grad(void* stream, int dtype, int n, int d, int p, int q_local,
                   const void* x, const void* Y, const void* sr,
-                  const double* theta, void* workspace, double* out, const lcgp_sched* sched);
+                  const double* theta, void* workspace, double* out, const lcgp_sched* sched,
+                  const void* plan_host /*or NULL*/, const void* plan_dev /*or NULL*/);
+
+/* The launch plan of the factorisation, computed ONCE by the caller instead of in every evaluation (it depends on
+ * dtype, n, q_local, the schedule and on whether the inverse follows -- with_inverse = 1 for lcgp_nll_grad, 0 for
+ * lcgp_potrf_logdet -- and on nothing else).  The plan is a position-independent block of `bytes` bytes in HOST memory
+ * owned by the caller; the caller also keeps a copy of the same bytes in DEVICE memory (any copy it likes) and passes
+ * both pointers to lcgp_nll_grad / lcgp_potrf_logdet, whose `sched` argument is then ignored (the plan carries the
+ * schedule it was built for).  plan_host = NULL: the plan is computed per call as before.  The library still keeps no
+ * state.  Replaces nothing in the reference: it is the cost of ~120 kernel launches the reference never had.
+ * lcgp_plan_info: launches of the launch-by-launch form, segments / tasks of the persistent form (0 when that form is
+ * not available for this plan), and what the plan leaves behind the factorisation (0 = L, 1 = and L^-1, 2 = and A^-1). */
+int lcgp_plan_bytes(int dtype, int n, int q_local, int with_inverse, const lcgp_sched* sched, size_t* bytes /*host out*/);
+int lcgp_plan_build(int dtype, int n, int q_local, int with_inverse, const lcgp_sched* sched,
+                    void* plan /*host out*/, size_t bytes);
+int lcgp_plan_info(const void* plan /*host*/, int* nlaunch, int* nseg, int* ntasks, int* inverse_done);
 
 /* Assembles this rank's share of the vector the ranks all-reduce (in the reference the sum over
  * k of lcgp.py:650-661 and the gradient tape's accumulation), on the device, in a fixed summation order:

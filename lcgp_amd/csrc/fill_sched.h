@@ -496,6 +496,252 @@ class Planner {
     }
 };
 
+// ---------------------------------------------------------------------------------------------------
+// The same plan as a task graph for ONE persistent launch (lcgp_hip.hip: dag_kernel).
+//
+// A SEGMENT is what a launch (or one filler job of a launch) is in the launch-by-launch executor: a kind, its integer
+// parameters and a number of workgroup-sized TASKS, enumerated exactly like the blocks of that launch.  All tasks of
+// the graph form one global sequence (segment after segment); the workgroups of the persistent kernel take them in that
+// order from one counter, so a task that has been taken is held by a RUNNING workgroup and everything it may wait for
+// lies before it in the sequence: the earliest unfinished task can always run, whatever number of workgroups is
+// resident (no co-residency assumption, no deadlock).
+// Dependencies are per (segment, component): a task of component k starts when the counters cnt[dep, k] of the
+// segments listed in `dep` have reached `need` (all tasks of that segment and component have finished); when it ends it
+// adds one to cnt[own segment, k].  The lists are DERIVED here from the blocks each segment reads and writes
+// (rectangles of 64x64 blocks per matrix; a conflict is an overlap with at least one writer: read-after-write,
+// write-after-write and write-after-read alike) and reduced transitively.  tests/test_fill_sched.py replays the graph
+// on numpy matrices and checks every block-level hazard against the declared lists.
+// ---------------------------------------------------------------------------------------------------
+constexpr int DAG_MAXDEP = 8;
+
+enum SegKind { S_LEAF = 1, S_STEP = 2, S_TRAIL = 3, S_FILL = 4 };
+
+struct DagSeg {
+    int kind;
+    int t0, ntasks;          // task ids [t0, t0 + ntasks)
+    int per_comp;            // tasks per component (= what cnt[this segment, k] reaches)
+    int k_off;               // component of task b (index within the segment): b < k_off ? b : (b - k_off) % q
+    int ndeps;
+    int dep[DAG_MAXDEP];     // segment indices (all smaller than this segment's)
+    int need[DAG_MAXDEP];    // their per_comp
+    int J, pe, c, diag_end, has_special, n_trmm, n_upd;      // S_LEAF (J) / S_STEP
+    int c_lo, c_hi, tiles128, with_leaf;                     // S_TRAIL (+ J, pe)
+    FillJob job;                                             // S_FILL
+};
+
+enum { BUF_M = 0, BUF_W = 1, BUF_V = 2, BUF_STAT = 3 };
+
+struct Access {
+    int buf, r0, r1, c0, c1;     // blocks [r0, r1) x [c0, c1) of one component's matrix
+    bool write;
+};
+
+class DagBuilder {
+ public:
+    std::vector<DagSeg> segs;
+    std::vector<std::vector<Access>> acc;     // per segment (kept for the dump / tests)
+    int ntasks = 0;
+    bool failed = false;
+
+    DagBuilder(int nb_, int q_) : nb(nb_), q(q_) {}
+
+    void build(const std::vector<Launch>& launches) {
+        for (const Launch& l : launches) {
+            if (l.kind == L_LEAF) {
+                DagSeg s = blank(S_LEAF);
+                s.J = l.J; s.pe = l.pe;
+                s.ntasks = q; s.per_comp = 1; s.k_off = q;
+                std::vector<Access> a;
+                leaf_access(a, l.J);
+                push(s, a);
+            } else if (l.kind == L_STEP) {
+                DagSeg s = blank(S_STEP);
+                s.J = l.J; s.pe = l.pe; s.c = l.c; s.diag_end = l.diag_end; s.has_special = l.has_special;
+                s.n_trmm = l.n_trmm; s.n_upd = l.n_upd;
+                s.per_comp = l.n_trmm + l.n_upd;
+                s.ntasks = s.per_comp * q;
+                s.k_off = l.has_special ? q : 0;
+                std::vector<Access> a;
+                step_access(a, l);
+                if (s.ntasks > 0) push(s, a);
+            } else if (l.kind == L_TRAIL) {
+                DagSeg s = blank(S_TRAIL);
+                s.J = l.J; s.pe = l.pe; s.c_lo = l.c_lo; s.c_hi = l.c_hi; s.tiles128 = l.tiles128; s.with_leaf = l.with_leaf;
+                const int nt = l.tiles128 ? trapezoid_tiles(nb / 2, l.c_lo / 2, l.c_hi / 2) + (l.with_leaf ? 1 : 0)
+                                          : trapezoid_tiles(nb, l.c_lo, l.c_hi);
+                s.per_comp = nt;
+                s.ntasks = nt * q;
+                s.k_off = l.with_leaf ? q : 0;
+                std::vector<Access> a;
+                a.push_back({BUF_M, l.c_lo, nb, l.J, l.pe, false});
+                a.push_back({BUF_M, l.c_lo, nb, l.c_lo, l.c_hi, true});
+                if (l.with_leaf) leaf_access(a, l.c_lo);
+                push(s, a);
+            }
+            for (int i = 0; i < l.fs.njobs; ++i) {
+                const FillJob& jb = l.fs.job[i];
+                if (jb.nblk <= 0) continue;
+                DagSeg s = blank(S_FILL);
+                s.job = jb;
+                s.ntasks = jb.nblk; s.per_comp = jb.nblk / q; s.k_off = 0;
+                std::vector<Access> a;
+                job_access(a, jb);
+                push(s, a);
+            }
+        }
+        derive_deps();
+    }
+
+ private:
+    int nb, q;
+
+    static DagSeg blank(int kind) {
+        DagSeg s;
+        s.kind = kind; s.t0 = 0; s.ntasks = 0; s.per_comp = 0; s.k_off = 0; s.ndeps = 0;
+        for (int i = 0; i < DAG_MAXDEP; ++i) { s.dep[i] = -1; s.need[i] = 0; }
+        s.J = s.pe = s.c = s.diag_end = s.has_special = s.n_trmm = s.n_upd = 0;
+        s.c_lo = s.c_hi = s.tiles128 = s.with_leaf = 0;
+        s.job.type = FILL_NONE; s.job.nblk = 0; s.job.t0 = 0; s.job.R0 = s.job.R1 = s.job.j0 = s.job.j1 = 0;
+        s.job.kb0 = s.job.kb1 = 0;
+        return s;
+    }
+
+    void push(DagSeg& s, const std::vector<Access>& a) {
+        s.t0 = ntasks;
+        ntasks += s.ntasks;
+        segs.push_back(s);
+        acc.push_back(a);
+    }
+
+    // diagonal block j: factor in place, inverse into W (and the zero quadrant beside an even block), running statistics
+    void leaf_access(std::vector<Access>& a, int j) const {
+        a.push_back({BUF_M, j, j + 1, j, j + 1, true});
+        a.push_back({BUF_W, j, j + 1, j, j + 1, true});
+        if ((j & 1) == 0 && j + 1 < nb) a.push_back({BUF_W, j, j + 1, j + 1, j + 2, true});
+        a.push_back({BUF_STAT, 0, 1, 0, 1, true});
+    }
+
+    void step_access(std::vector<Access>& a, const Launch& l) const {
+        const int c = l.c;
+        a.push_back({BUF_W, c, c + 1, c, c + 1, false});
+        if (c > l.J) a.push_back({BUF_M, c, nb, c - 1, c, false});            // L[c, c-1] and L[r, c-1]
+        a.push_back({BUF_M, c + 1, nb, c, c + 1, true});                     // the block column itself
+        const int de = l.diag_end < nb ? l.diag_end : nb;
+        for (int r = c + 1; r < de; ++r) a.push_back({BUF_M, r, r + 1, r, r + 1, true});
+        if (l.has_special) leaf_access(a, c + 1);
+        if (l.n_upd > 0) {
+            a.push_back({BUF_M, c + 2, nb, c + 1, c + 2, true});
+            if (c > l.J) a.push_back({BUF_M, c + 1, nb, l.J, c, false});
+        }
+    }
+
+    // blocks touched by the tiles [t0, t0 + nblk / q) of a filler job (bounding rectangles; see the enumerations above)
+    void job_access(std::vector<Access>& a, const FillJob& jb) const {
+        const long n = jb.nblk / q;
+        const int kb0 = jb.kb0, kb1 = jb.kb1;
+        if (jb.type == FILL_SYRK) {
+            // column-major over j, rows R in [j / 2, R1): per column touched one rectangle
+            long t = jb.t0;
+            int j = jb.j0;
+            while (t >= jb.R1 - (j >> 1)) { t -= jb.R1 - (j >> 1); ++j; }
+            long left = n;
+            while (left > 0 && j < jb.j1) {
+                const long in_col = jb.R1 - (j >> 1) - t;
+                const long take = left < in_col ? left : in_col;
+                const int Ra = (j >> 1) + (int)t, Rb = Ra + (int)take;
+                a.push_back({BUF_M, 2 * Ra, 2 * Rb, j, j + 1, true});
+                a.push_back({BUF_M, 2 * Ra, 2 * Rb, kb0, kb1, false});
+                a.push_back({BUF_M, j, j + 1, kb0, kb1, false});
+                left -= take; t = 0; ++j;
+            }
+        } else if (jb.type == FILL_BROW || jb.type == FILL_CUPD) {
+            const int nc = jb.j1 - jb.j0;
+            long t = jb.t0, left = n;
+            while (left > 0) {
+                const int R = jb.R0 + (int)(t / nc), ja = jb.j0 + (int)(t % nc);
+                const long in_row = nc - (t % nc);
+                const long take = left < in_row ? left : in_row;
+                const int jz = ja + (int)take;
+                if (jb.type == FILL_BROW) {
+                    const int ke = kb1 < 2 * R + 2 ? kb1 : 2 * R + 2;
+                    a.push_back({BUF_W, 2 * R, 2 * R + 2, ja, jz, true});
+                    a.push_back({BUF_W, 2 * R, 2 * R + 2, kb0, ke, false});
+                    a.push_back({BUF_V, kb0, ke, ja, jz, false});
+                } else {
+                    a.push_back({BUF_V, 2 * R, 2 * R + 2, ja, jz, true});
+                    a.push_back({BUF_M, 2 * R, 2 * R + 2, kb0, kb1, false});
+                    a.push_back({BUF_W, kb0, kb1, ja, jz, false});
+                }
+                left -= take; t += take;
+            }
+        } else if (jb.type == FILL_DUPD) {
+            long t = jb.t0, left = n;
+            while (left > 0) {
+                int R = 0;
+                while ((long)(R + 1) * (R + 2) <= t) ++R;
+                const int ja = (int)(t - (long)R * (R + 1));
+                const long in_row = 2 * R + 2 - ja;
+                const long take = left < in_row ? left : in_row;
+                const int jz = ja + (int)take;
+                const int ks = 2 * R >= kb0 ? 2 * R : kb0;
+                a.push_back({BUF_V, 2 * R, 2 * R + 2, ja, jz, true});
+                a.push_back({BUF_W, ks, kb1, 2 * R, 2 * R + 2, false});
+                a.push_back({BUF_W, ks, kb1, ja, jz, false});
+                left -= take; t += take;
+            }
+        } else {
+            // TRI_T / TRI_W: one level of the block inverse, pairs [j0, j0 + R1) of block size mb = R0 (the whole level:
+            // a job of a level is small)
+            const int mb = jb.R0;
+            for (int pr = jb.j0; pr < jb.j0 + jb.R1; ++pr) {
+                const int C0 = 2 * pr * mb, R0 = C0 + mb;
+                const int Re = R0 + mb < nb ? R0 + mb : nb;
+                if (R0 >= nb) continue;
+                if (jb.type == FILL_TRI_T) {
+                    a.push_back({BUF_M, R0, Re, C0, R0, false});
+                    a.push_back({BUF_W, C0, R0, C0, R0, false});
+                    a.push_back({BUF_V, R0, Re, C0, R0, true});
+                } else {
+                    a.push_back({BUF_W, R0, Re, R0, Re, false});
+                    a.push_back({BUF_V, R0, Re, C0, R0, false});
+                    a.push_back({BUF_W, R0, Re, C0, R0, true});
+                }
+            }
+        }
+    }
+
+    static bool overlap(const Access& x, const Access& y) {
+        return x.buf == y.buf && (x.write || y.write) && x.r0 < y.r1 && y.r0 < x.r1 && x.c0 < y.c1 && y.c0 < x.c1;
+    }
+    bool conflict(int s, int t) const {
+        for (const Access& x : acc[s])
+            for (const Access& y : acc[t])
+                if (overlap(x, y)) return true;
+        return false;
+    }
+
+    void derive_deps() {
+        const int ns = (int)segs.size();
+        const int nw = (ns + 63) / 64;
+        std::vector<unsigned long long> clo((size_t)ns * nw, 0ull);      // transitive closure of the kept dependencies
+        for (int s = 0; s < ns; ++s) {
+            unsigned long long* cs = &clo[(size_t)s * nw];
+            for (int t = s - 1; t >= 0; --t) {
+                if ((cs[t >> 6] >> (t & 63)) & 1ull) continue;            // already implied
+                if (!conflict(t, s)) continue;
+                DagSeg& sg = segs[s];
+                if (sg.ndeps >= DAG_MAXDEP) { failed = true; return; }
+                sg.dep[sg.ndeps] = t;
+                sg.need[sg.ndeps] = segs[t].per_comp;
+                ++sg.ndeps;
+                cs[t >> 6] |= 1ull << (t & 63);
+                const unsigned long long* ct = &clo[(size_t)t * nw];
+                for (int w = 0; w < nw; ++w) cs[w] |= ct[w];
+            }
+        }
+    }
+};
+
 }  // namespace lcgp_fill
 
 #endif

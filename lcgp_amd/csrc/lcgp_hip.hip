@@ -17,11 +17,12 @@
 #include <stdio.h>
 #include <string.h>
 #include <math.h>
+#include <vector>
 
 #include "../../include/lcgp_hip.h"
 #include "fill_sched.h"
 
-#define LCGP_VERSION 200
+#define LCGP_VERSION 300
 
 namespace {
 
@@ -55,11 +56,15 @@ struct Ws {
     size_t esz;
     size_t mat;          // elements per matrix
     char* base;
-    size_t off_M, off_W, off_V, off_b, off_z, off_part, off_cpart, off_c, off_logdet, off_info, total;
+    size_t off_M, off_W, off_V, off_b, off_z, off_part, off_cpart, off_c, off_logdet, off_info, off_dag, total;
     int ntile_lower;
 };
 
 inline size_t align256(size_t x) { return (x + 255) & ~size_t(255); }
+
+// control words of the persistent factorisation launch (dag_kernel): 16 ints + one counter per (segment, component); the
+// bound on the segments of a plan follows from fill_sched.h (launches <= 8 nb + 16, at most 1 + NJ segments per launch)
+inline size_t dag_ctl_ints(int nb, int q) { return 16 + (size_t)(56 * nb + 112) * q; }
 
 inline Ws carve(int dtype, int n, int d, int p, int q, void* base) {
     Ws w;
@@ -83,6 +88,7 @@ inline Ws carve(int dtype, int n, int d, int p, int q, void* base) {
     w.off_c = o; o = align256(o + (dtype == LCGP_F64 ? 0 : (size_t)w.npad * q * sizeof(double)));
     w.off_logdet = o; o = align256(o + (size_t)q * sizeof(double));
     w.off_info = o; o = align256(o + (size_t)q * sizeof(int));
+    w.off_dag = o; o = align256(o + dag_ctl_ints(w.nb, q) * sizeof(int));
     w.total = o;
     return w;
 }
@@ -106,6 +112,21 @@ template <> struct Mfma<float> {
     }
     static __device__ __forceinline__ int row(int lane, int reg) { return (lane >> 4) * 4 + reg; }
 };
+
+// Thread index of a tile body.  Opaque to the optimiser on purpose: inside the persistent kernel (dag_kernel) the bodies
+// sit in a loop, and with the plain intrinsic every lane-dependent address computation of every body is hoisted in front
+// of that loop and kept alive across it (149 spilled registers in the fp64 build).
+__device__ __forceinline__ int body_tid() {
+    int t = threadIdx.x;
+    asm volatile("" : "+v"(t));
+    __builtin_assume(t >= 0 && t < 1024);
+    return t;
+}
+// the same for a wave-uniform value that comes from the kernel arguments
+__device__ __forceinline__ int opaque_s(int v) {
+    asm volatile("" : "+s"(v));
+    return v;
+}
 
 __device__ __forceinline__ void tri_decode(int t, int& r, int& c) {
     int rr = (int)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
@@ -514,7 +535,7 @@ template <typename T, bool FROM_LDS>
 __device__ __forceinline__ void leaf_factor_invert(T* __restrict__ Mb, T* __restrict__ Wb, int npad, double (*lt)[LEAF_LDT],
                                                    double (*w)[LEAF_LDT], double* scratch, double* dinv, double* pivs,
                                                    int* bad, int jb) {
-    const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tid = body_tid(), lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 15, lq = lane >> 4;
     d4 acc[4];
 #pragma unroll
@@ -610,7 +631,7 @@ __device__ __forceinline__ void leaf_body(unsigned char* lds, int k, T* __restri
     double* dinv = scratch + LEAF_SCR;
     double* pivs = dinv + TS;
     int* bad = (int*)(pivs + TS);
-    const int tid = threadIdx.x;
+    const int tid = body_tid();
     T* Mb = M + (size_t)k * mat + (size_t)jb * TS * npad + (size_t)jb * TS;
     T* Wb = W + (size_t)k * mat + (size_t)jb * TS * npad + (size_t)jb * TS;
     // the running log-determinant and status of the component are fetched now, so that the end is a store, not a round trip
@@ -841,7 +862,7 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, const int lin /*blo
         Ct = Cb + (size_t)m * TM * g.ldC + (size_t)r * TM;
     }
 
-    const int tid = threadIdx.x;
+    const int tid = body_tid();
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave-uniform: the sub-tile origin (wm0, wn0) stays in SGPRs
     const int wm0 = (wave >> 1) * WTM, wn0 = (wave & 1) * WTN;
@@ -1059,7 +1080,7 @@ __device__ __forceinline__ void rect_tile(const T* __restrict__ A0, int ldA, con
     constexpr int EA = TMR * KT / NT, EB = TNC * KT / NT;
     T* As = (T*)lds;                   // [2][KT * LDA]
     T* Bs = As + 2 * KT * LDA;         // [2][KT * LDB]
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tid = body_tid(), lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm0 = (wave >> 1) * 64, wn0 = (wave & 1) * 32;
     typedef typename Mfma<T>::acc_t acc_t;
     acc_t acc[4][2];
@@ -1402,11 +1423,9 @@ struct Tile64 {          // 64x64 tile on 256 threads: wave (wm, wn) owns a 32x3
 };
 
 template <typename T>
-__global__ __launch_bounds__(256, 2) void chain_step_kernel(StepArgs a) {
-    __shared__ __align__(16) unsigned char lds[LEAF_LDS_BYTES];
+__device__ __forceinline__ void chain_step_body(const StepArgs& a, int b, unsigned char* lds) {
     typedef Tile64<T> TL;
-    int b = blockIdx.x;
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tid = body_tid(), lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm0 = (wave >> 1) * 32, wn0 = (wave & 1) * 32;
     const int ld = a.npad;
     // block order = longest first: the special tiles (chain of the step), the filler tiles, then the short ones
@@ -1507,6 +1526,12 @@ __global__ __launch_bounds__(256, 2) void chain_step_kernel(StepArgs a) {
     }
 }
 
+template <typename T>
+__global__ __launch_bounds__(256, 2) void chain_step_kernel(StepArgs a) {
+    __shared__ __align__(16) unsigned char lds[LEAF_LDS_BYTES];
+    chain_step_body<T>(a, blockIdx.x, lds);
+}
+
 // Trailing update of a panel that also factors the FIRST diagonal block of the next panel: the first q workgroups run
 // leaf_body on that 64x64 block (the chain steps of the panel have already applied the panel to it: diag_end = pe + 1),
 // the others are the tiles of the wide update (tile 0 of the 128-tile form leaves that quadrant alone; the 64-tile form
@@ -1524,6 +1549,136 @@ __global__ __launch_bounds__(256, 2) void wide_leaf_kernel(GemmArgs g, T* __rest
         return;
     }
     gemm_body<T, OP_SYRK, TM, 4>(g, blockIdx.x - q, lds);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// The factorisation as ONE persistent launch with dependencies inside it (fill_sched.h: DagBuilder).
+//
+// The launch-by-launch executor orders everything by kernel boundaries: all components move in lock step, a trailing
+// update ends in a partially filled round of tiles, and a chain launch lasts as long as its slowest workgroup.  Here the
+// same work items (the blocks of those launches, same bodies, same arithmetic) form one global task sequence; the
+// workgroups take the tasks in sequence order from one counter and a task waits only for what it reads or overwrites:
+//   * per (segment, component) a counter of finished tasks in the caller-owned workspace (zeroed by a memset node in
+//     front of the launch; the library still has no state);
+//   * a task of component k polls the counters of its segment's dependencies (<= 8, one lane each, relaxed agent-scope
+//     loads with s_sleep; BOUNDED: on expiry the failure word is set, every later wait returns at once, the launch
+//     drains and the components report info = -1), then ONE agent-scope acquire (buffer_inv sc1) and a workgroup
+//     barrier, then plain loads;
+//   * at its end every wave drains its stores (s_waitcnt vmcnt(0)), the workgroup meets at a barrier, and one lane
+//     publishes: agent-scope release (buffer_wbl2 sc1), s_waitcnt vmcnt(0) written as asm (ROCm 7.2 can drop the
+//     fence's own wait), then the relaxed atomic add on the counter  (MI355X_MICROARCH.md, inter-workgroup visibility).
+// Progress does not depend on how many workgroups are resident: a task that has been taken is held by a running
+// workgroup and only waits for tasks before it in the sequence, so the earliest unfinished task can always run.
+// ---------------------------------------------------------------------------------------------------
+constexpr int DAG_CTL = 16;       // ints in front of the counters: [0] next task, [1] failure word
+using lcgp_fill::DagSeg;
+
+struct DagArgs {
+    void* M; void* W; void* V; size_t mat; int npad, nb, q;
+    double* logdet; int* info;
+    const DagSeg* segs; int nseg; int ntasks;
+    int* ctl;
+    unsigned spin_limit;
+};
+
+__device__ __forceinline__ int dag_load(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+template <typename T>
+__global__ __launch_bounds__(256, 2) void dag_kernel(DagArgs a) {
+    constexpr int WIDE_LDS = 4 * KT * (128 + 16) * (int)sizeof(T);
+    __shared__ __align__(16) unsigned char lds[WIDE_LDS > LEAF_LDS_BYTES ? WIDE_LDS : LEAF_LDS_BYTES];
+    __shared__ int sh_task;
+    const int tid = threadIdx.x;
+    const DagSeg* __restrict__ segs = a.segs;
+    int* cnt = a.ctl + DAG_CTL;
+    int seg = 0, memo_seg = -1, memo_k = -1;
+    for (;;) {
+        if (tid == 0) sh_task = __hip_atomic_fetch_add(&a.ctl[0], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        const int t = __builtin_amdgcn_readfirstlane(sh_task);
+        if (t >= a.ntasks) break;
+        while (t >= segs[seg].t0 + segs[seg].ntasks) ++seg;
+        const DagSeg& sg = segs[seg];
+        const int b = t - sg.t0;
+        const int k = b < sg.k_off ? b : (b - sg.k_off) % a.q;
+        if (seg != memo_seg || k != memo_k) {
+            // (a workgroup that has already waited for this segment and component has seen everything they depend on)
+            if (tid < sg.ndeps) {
+                const int* c = cnt + (size_t)sg.dep[tid] * a.q + k;
+                const int need = sg.need[tid];
+                unsigned it = 0;
+                while (dag_load(c) < need) {
+                    __builtin_amdgcn_s_sleep(4);
+                    ++it;
+                    if (it > a.spin_limit || ((it & 255u) == 0 && dag_load(&a.ctl[1]) != 0)) {
+                        __hip_atomic_store(&a.ctl[1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        break;
+                    }
+                }
+            }
+            if (tid < 64) {      // the polling lanes are lanes of wave 0: its lane 0 fences after all of them have matched
+                if (tid == 0) {
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                }
+            }
+            __syncthreads();
+            memo_seg = seg;
+            memo_k = k;
+        }
+        T* M = (T*)a.M;
+        T* W = (T*)a.W;
+        // (opaque copies: what the bodies derive from these would otherwise be computed once in front of the loop for all
+        // bodies together and held in registers across it)
+        const int npad = opaque_s(a.npad), nbk = opaque_s(a.nb), q = opaque_s(a.q);
+        const size_t mat = (size_t)npad * npad;
+        if (sg.kind == lcgp_fill::S_LEAF) {
+            leaf_body<T>(lds, k, M, W, mat, npad, sg.J, a.logdet, a.info);
+        } else if (sg.kind == lcgp_fill::S_STEP) {
+            StepArgs sa;
+            sa.M = a.M; sa.W = a.W; sa.mat = mat; sa.npad = npad; sa.nb = nbk;
+            sa.c = sg.c; sa.J = sg.J; sa.pe = sg.pe; sa.diag_end = sg.diag_end; sa.q = q;
+            sa.has_special = sg.has_special; sa.n_trmm = sg.n_trmm; sa.n_upd = sg.n_upd;
+            sa.logdet = a.logdet; sa.info = a.info;
+            sa.fs.njobs = 0; sa.fs.nblk = 0;
+            chain_step_body<T>(sa, b, lds);
+            __builtin_amdgcn_s_setprio(0);
+        } else if (sg.kind == lcgp_fill::S_TRAIL) {
+            if (sg.with_leaf && b < q) {
+                leaf_body<T>(lds, b, M, W, mat, npad, sg.c_lo, a.logdet, a.info);
+            } else {
+                GemmArgs g;
+                g.sA = g.sB = g.sC = mat; g.ldA = g.ldB = g.ldC = npad;
+                g.A = a.M; g.B = a.M; g.C = a.M;
+                g.q = q;
+                const int lin = b - (sg.with_leaf ? q : 0);
+                if (sg.tiles128) {
+                    g.nb = nbk / 2; g.p0 = sg.J / 2; g.p1 = sg.pe / 2; g.p2 = sg.c_lo / 2; g.p3 = sg.c_hi / 2;
+                    g.t0 = 0; g.skipq = sg.with_leaf;
+                    gemm_body<T, OP_SYRK, 128, 4>(g, lin, lds);
+                } else {
+                    g.nb = nbk; g.p0 = sg.J; g.p1 = sg.pe; g.p2 = sg.c_lo; g.p3 = sg.c_hi;
+                    g.t0 = sg.with_leaf ? 1 : 0; g.skipq = 0;
+                    gemm_body<T, OP_SYRK, 64, 4>(g, lin, lds);
+                }
+            }
+        } else {
+            FillSet fs;
+            fs.M = a.M; fs.W = a.W; fs.V = a.V; fs.mat = mat; fs.npad = npad; fs.nb = nbk; fs.q = q;
+            fs.njobs = 1; fs.nblk = sg.job.nblk;
+            fs.job[0] = sg.job;
+            fill_dispatch<T>(fs, b, lds);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // every wave: its stores have left
+        __syncthreads();
+        if (tid == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __hip_atomic_fetch_add(cnt + (size_t)seg * a.q + k, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    if (dag_load(&a.ctl[1]) != 0)
+        for (int k = tid; k < a.q; k += 256) a.info[k] = -1;
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -2136,13 +2291,17 @@ inline lcgp_sched default_sched() {
     s.progressive_lauum = 48;      // ... and A^-1 = W^T W accumulated behind the chain as well up to this many 64-blocks per side
                                    // (n = 2048: 1.12 -> 0.98 ms; at n = 4096 its tail is one ragged launch of long K loops
                                    // that loses to the one-launch W^T W: 2.54 vs 2.43 ms)
+    s.dag = 0;                     // 1 = with a plan (lcgp_plan_build) the factorisation runs as ONE persistent launch with
+                                   // dependencies inside it (dag_kernel) instead of launch by launch
+    s.dag_spin_limit = 0;          // polls of one wait in that launch before it gives up (0 = 2,000,000, about two seconds)
     return s;
 }
 
 inline int check_sched(const lcgp_sched& s) {
     if (s.outer_blocks < 0 || s.outer_blocks > 64) return bad("sched.outer_blocks must be in [0, 64]");
     if (s.syrk_small_tiles < 0 || s.trtri_small_tiles < 0 || s.lauum_small_tiles < 0 || s.trtri_level_small < 0 ||
-        s.fill_leaf < 0 || s.fill_step < 0 || s.leaf_in_wide < 0 || s.progressive_tiles < 0 || s.progressive_lauum < 0)
+        s.fill_leaf < 0 || s.fill_step < 0 || s.leaf_in_wide < 0 || s.progressive_tiles < 0 || s.progressive_lauum < 0 ||
+        s.dag < 0 || s.dag_spin_limit < 0)
         return bad("sched fields must be >= 0");
     return 0;
 }
@@ -2196,13 +2355,83 @@ int potrf_trailing(hipStream_t st, const Ws& w, int J, int pe, int c_lo, int c_h
     return launch_gemm<T, OP_SYRK>(st, g, nt, w.q);
 }
 
-// progressive inverse behind the chain (fill_sched.h): worth it when the chain launches have room for its jobs, i.e. with
-// few components per rank (sched.progressive_tiles: at most this many 128x128 lower tiles x components; needs a panel
-// width that is a power of two so that the levels of the block inverse stay inside a panel)
-inline bool use_progressive(const Ws& w, const lcgp_sched& sc, int ob) {
-    if (sc.progressive_tiles <= 0 || ob < 2 || (ob & (ob - 1)) != 0) return false;
-    const int nb2 = w.nb / 2;
-    return (long long)w.q * (nb2 * (nb2 + 1) / 2) <= sc.progressive_tiles;
+// ---- the plan of a factorisation as a caller-owned, position-independent block of bytes (lcgp_plan_build) ----
+// header | Launch[nlaunch] (the launch-by-launch executor) | DagSeg[nseg] (the persistent launch; this part is what the
+// kernel reads, from the caller's DEVICE copy of the same bytes).  It depends on (dtype, n, q_local, with_inverse, sched)
+// only, so a caller builds it once and passes it with every evaluation: no planning in the evaluation loop.
+constexpr unsigned PLAN_MAGIC = 0x4c43504cu;
+struct PlanHeader {
+    unsigned magic;
+    int version;
+    int dtype, n, nb, q, with_inverse;
+    int nlaunch, nseg, ntasks;
+    int inverse_done;          // what the plan leaves behind the factorisation: 0 = L, 1 = and L^-1, 2 = and A^-1
+    int num_cu;
+    lcgp_sched sched;
+    size_t off_launch, off_seg, bytes;
+};
+
+inline lcgp_fill::PlanParams plan_params(int dtype, int nb, int q, bool with_inverse, const lcgp_sched& sc, int* inverse_done) {
+    lcgp_fill::PlanParams pp;
+    pp.nb = nb; pp.q = q;
+    pp.ob = sc.outer_blocks < 1 ? (dtype == LCGP_F32 ? 8 : 4) : sc.outer_blocks;
+    pp.syrk_small_tiles = sc.syrk_small_tiles; pp.fill_leaf = sc.fill_leaf; pp.fill_step = sc.fill_step;
+    pp.leaf_in_wide = sc.leaf_in_wide;
+    bool prog = false;
+    if (with_inverse && sc.progressive_tiles > 0 && pp.ob >= 2 && (pp.ob & (pp.ob - 1)) == 0) {
+        const int nb2 = nb / 2;
+        prog = (long long)q * (nb2 * (nb2 + 1) / 2) <= sc.progressive_tiles;
+    }
+    pp.progressive = prog;
+    pp.far_rides = !(pp.progressive && sc.progressive_far == 0);
+    pp.with_dupd = nb <= sc.progressive_lauum;
+    if (inverse_done) *inverse_done = pp.progressive ? (pp.with_dupd ? 2 : 1) : 0;
+    return pp;
+}
+
+// builds the plan into `out` (NULL: only the size is computed); returns the bytes, 0 on failure
+inline size_t make_plan(int dtype, int n, int q, bool with_inverse, const lcgp_sched& sc, void* out) {
+    const int npad = round_up(n, 2 * TS), nb = npad / TS;
+    int inverse_done = 0;
+    lcgp_fill::Planner plan(plan_params(dtype, nb, q, with_inverse, sc, &inverse_done));
+    plan.run();
+    if (plan.failed) { bad("internal: the filler queue did not drain"); return 0; }
+    lcgp_fill::DagBuilder dag(nb, q);
+    dag.build(plan.launches);
+    const bool dag_ok = !dag.failed && dag.segs.size() * (size_t)q + 16 <= dag_ctl_ints(nb, q);
+    PlanHeader h;
+    memset(&h, 0, sizeof(h));
+    h.magic = PLAN_MAGIC; h.version = LCGP_VERSION;
+    h.dtype = dtype; h.n = n; h.nb = nb; h.q = q; h.with_inverse = with_inverse ? 1 : 0;
+    h.nlaunch = (int)plan.launches.size();
+    h.nseg = dag_ok ? (int)dag.segs.size() : 0;
+    h.ntasks = dag_ok ? dag.ntasks : 0;
+    h.inverse_done = inverse_done;
+    h.sched = sc;
+    int dev = 0, ncu = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
+        ncu < 1)
+        ncu = 256;
+    (void)hipGetLastError();
+    h.num_cu = ncu;
+    h.off_launch = (sizeof(PlanHeader) + 255) & ~size_t(255);
+    h.off_seg = (h.off_launch + sizeof(lcgp_fill::Launch) * h.nlaunch + 255) & ~size_t(255);
+    h.bytes = (h.off_seg + sizeof(DagSeg) * h.nseg + 255) & ~size_t(255);
+    if (out) {
+        memset(out, 0, h.bytes);
+        memcpy(out, &h, sizeof(h));
+        memcpy((char*)out + h.off_launch, plan.launches.data(), sizeof(lcgp_fill::Launch) * h.nlaunch);
+        if (h.nseg) memcpy((char*)out + h.off_seg, dag.segs.data(), sizeof(DagSeg) * h.nseg);
+    }
+    return h.bytes;
+}
+
+inline int check_plan(const void* plan_host, int dtype, int n, int q, bool with_inverse) {
+    const PlanHeader* h = (const PlanHeader*)plan_host;
+    if (h->magic != PLAN_MAGIC || h->version != LCGP_VERSION) return bad("plan: not a plan of this library version");
+    if (h->dtype != dtype || h->n != n || h->q != q || h->with_inverse != (with_inverse ? 1 : 0))
+        return bad("plan: built for another (dtype, n, q_local, with_inverse)");
+    return 0;
 }
 
 // Two-level right-looking Cholesky.  Outer panels of `ob` 64-blocks: inside a panel every 64-column step is ONE launch
@@ -2211,10 +2440,13 @@ inline bool use_progressive(const Ws& w, const lcgp_sched& sc, int ob) {
 // launch (the columns of panel J+1 and as many more as do not fit below) and its right-most columns, which the chain
 // launches of panel J+1 carry as filler tiles -- the chain leaves >= 97 % of the CUs idle, and a second HIP stream
 // cannot fill them on this platform.  The launch sequence is PLANNED first (fill_sched.h: Planner, host
-// only, also replayed on the CPU by tests/native/test_fill_sched.cpp) and then enqueued here launch by launch.
+// only, replayed on the CPU by tests/test_fill_sched.py through tests/native/dump_plan.cpp) -- by the caller, once
+// (lcgp_plan_build), or here per call when no plan is passed -- and then enqueued launch by launch, or, with a plan
+// whose schedule says so, as the one persistent launch of dag_kernel.
 template <typename T>
 int do_potrf(hipStream_t st, const Ws& w, const lcgp_sched& sc, bool stats_zeroed = false, bool with_inverse = false,
-             int* inverse_done = nullptr /* 0 = nothing, 1 = L^-1, 2 = L^-1 and A^-1 */) {
+             int* inverse_done = nullptr /* 0 = nothing, 1 = L^-1, 2 = L^-1 and A^-1 */, const void* plan_host = nullptr,
+             const void* plan_dev = nullptr) {
     T* M = (T*)(w.base + w.off_M);
     T* W = (T*)(w.base + w.off_W);
     double* logdet = (double*)(w.base + w.off_logdet);
@@ -2223,20 +2455,45 @@ int do_potrf(hipStream_t st, const Ws& w, const lcgp_sched& sc, bool stats_zeroe
         hipLaunchKernelGGL(zero_stats_kernel, dim3((w.q + 63) / 64), dim3(64), 0, st, logdet, info, w.q);
         CHECK_LAUNCH("zero_stats");
     }
-    lcgp_fill::PlanParams pp;
-    pp.nb = w.nb; pp.q = w.q;
-    pp.ob = sc.outer_blocks < 1 ? (sizeof(T) == 4 ? 8 : 4) : sc.outer_blocks;
-    pp.syrk_small_tiles = sc.syrk_small_tiles; pp.fill_leaf = sc.fill_leaf; pp.fill_step = sc.fill_step;
-    pp.leaf_in_wide = sc.leaf_in_wide;
-    pp.progressive = with_inverse && use_progressive(w, sc, pp.ob);
-    pp.far_rides = !(pp.progressive && sc.progressive_far == 0);
-    pp.with_dupd = w.nb <= sc.progressive_lauum;
-    if (inverse_done) *inverse_done = pp.progressive ? (pp.with_dupd ? 2 : 1) : 0;
-    lcgp_fill::Planner plan(pp);
-    plan.run();
-    if (plan.failed) return bad("internal: the filler queue did not drain");
-    for (lcgp_fill::Launch& l : plan.launches) {
-        FillSet& fs = l.fs;
+    const int dtype = sizeof(T) == 4 ? LCGP_F32 : LCGP_F64;
+    const lcgp_fill::Launch* launches = nullptr;
+    int nlaunch = 0;
+    std::vector<lcgp_fill::Launch> local;
+    if (plan_host) {
+        const PlanHeader* h = (const PlanHeader*)plan_host;
+        if (inverse_done) *inverse_done = h->inverse_done;
+        if (h->sched.dag && h->nseg > 0 && plan_dev) {
+            // ONE persistent launch: control words zeroed by a memset node, then as many workgroups as the chip holds
+            int* ctl = (int*)(w.base + w.off_dag);
+            const size_t zb = ((size_t)(DAG_CTL + (size_t)h->nseg * w.q) * sizeof(int) + 15) & ~size_t(15);
+            hipError_t e = hipMemsetAsync(ctl, 0, zb, st);
+            if (e != hipSuccess) return fail("hipMemsetAsync", e);
+            DagArgs a;
+            a.M = M; a.W = W; a.V = w.base + w.off_V; a.mat = w.mat; a.npad = w.npad; a.nb = w.nb; a.q = w.q;
+            a.logdet = logdet; a.info = info;
+            a.segs = (const DagSeg*)((const char*)plan_dev + h->off_seg);
+            a.nseg = h->nseg; a.ntasks = h->ntasks;
+            a.ctl = ctl;
+            a.spin_limit = h->sched.dag_spin_limit > 0 ? (unsigned)h->sched.dag_spin_limit : 2000000u;
+            long grid = 2L * h->num_cu;
+            if (grid > h->ntasks) grid = h->ntasks;
+            hipLaunchKernelGGL((dag_kernel<T>), dim3((unsigned)grid), dim3(256), 0, st, a);
+            CHECK_LAUNCH("dag_kernel");
+            return 0;
+        }
+        launches = (const lcgp_fill::Launch*)((const char*)plan_host + h->off_launch);
+        nlaunch = h->nlaunch;
+    } else {
+        lcgp_fill::Planner plan(plan_params(dtype, w.nb, w.q, with_inverse, sc, inverse_done));
+        plan.run();
+        if (plan.failed) return bad("internal: the filler queue did not drain");
+        local.swap(plan.launches);
+        launches = local.data();
+        nlaunch = (int)local.size();
+    }
+    for (int li = 0; li < nlaunch; ++li) {
+        const lcgp_fill::Launch& l = launches[li];
+        FillSet fs = l.fs;
         fs.M = w.base + w.off_M; fs.W = w.base + w.off_W; fs.V = w.base + w.off_V;
         fs.mat = w.mat; fs.npad = w.npad; fs.nb = w.nb; fs.q = w.q;
         int rc = 0;
@@ -2354,13 +2611,13 @@ void launch_grad(hipStream_t st, const Ws& w, const void* x, const void* sr, con
 
 template <typename T>
 int do_nll_grad(hipStream_t st, const Ws& w, const lcgp_sched& sc, const void* x, const void* Y, const void* sr,
-                const double* theta, double* out) {
+                const double* theta, double* out, const void* plan_host, const void* plan_dev) {
     int rc = do_build<T>(st, w, x, sr, theta, Y);
     if (rc) return rc;
     T* b = (T*)(w.base + w.off_b);
     T* z = (T*)(w.base + w.off_z);
     int inverse_done = 0;          // what the progressive inverse has left behind the factorisation: 1 = L^-1, 2 = and A^-1
-    rc = do_potrf<T>(st, w, sc, true, true, &inverse_done);
+    rc = do_potrf<T>(st, w, sc, true, true, &inverse_done, plan_host, plan_dev);
     if (rc) return rc;
     bool z_partials = false;       // z = A^-1 b: per-tile partials from the 128-tile LAUUM's epilogue, or a pass of its own
     if (inverse_done == 0) rc = do_potri<T>(st, w, sc, &z_partials);
@@ -2581,15 +2838,17 @@ int lcgp_kernel_build(void* stream, int dtype, int n, int d, int p, int q_local,
 }
 
 int lcgp_potrf_logdet(void* stream, int dtype, int n, int d, int p, int q_local, void* workspace, double* half_logdet,
-                      int* info, const lcgp_sched* sched) {
+                      int* info, const lcgp_sched* sched, const void* plan_host, const void* plan_dev) {
     int rc = check_common(dtype, n, d, p, q_local);
     if (rc) return rc;
     if (!workspace) return bad("NULL workspace");
     lcgp_sched sc;
     if ((rc = resolve_sched(sched, sc))) return rc;
+    if (plan_host && (rc = check_plan(plan_host, dtype, n, q_local, false))) return rc;
     Ws w = carve(dtype, n, d, p, q_local, workspace);
     hipStream_t st = (hipStream_t)stream;
-    rc = dtype == LCGP_F64 ? do_potrf<double>(st, w, sc) : do_potrf<float>(st, w, sc);
+    rc = dtype == LCGP_F64 ? do_potrf<double>(st, w, sc, false, false, nullptr, plan_host, plan_dev)
+                           : do_potrf<float>(st, w, sc, false, false, nullptr, plan_host, plan_dev);
     if (rc) return rc;
     if (half_logdet || info) {
         hipLaunchKernelGGL(copy_stats_kernel, dim3((q_local + 63) / 64), dim3(64), 0, st,
@@ -2664,15 +2923,55 @@ int lcgp_fetch_vector(void* stream, int dtype, int n, int d, int p, int q_local,
 }
 
 int lcgp_nll_grad(void* stream, int dtype, int n, int d, int p, int q_local, const void* x, const void* Y,
-                  const void* sr, const double* theta, void* workspace, double* out, const lcgp_sched* sched) {
+                  const void* sr, const double* theta, void* workspace, double* out, const lcgp_sched* sched,
+                  const void* plan_host, const void* plan_dev) {
     int rc = check_common(dtype, n, d, p, q_local);
     if (rc) return rc;
     if (!x || !Y || !theta || !workspace || !out) return bad("NULL pointer");
     lcgp_sched sc;
-    if ((rc = resolve_sched(sched, sc))) return rc;
+    if (plan_host) {
+        // the plan carries the schedule it was built for (the stages behind the factorisation read their thresholds there)
+        if ((rc = check_plan(plan_host, dtype, n, q_local, true))) return rc;
+        sc = ((const PlanHeader*)plan_host)->sched;
+    } else if ((rc = resolve_sched(sched, sc))) {
+        return rc;
+    }
     Ws w = carve(dtype, n, d, p, q_local, workspace);
-    return dtype == LCGP_F64 ? do_nll_grad<double>((hipStream_t)stream, w, sc, x, Y, sr, theta, out)
-                             : do_nll_grad<float>((hipStream_t)stream, w, sc, x, Y, sr, theta, out);
+    return dtype == LCGP_F64 ? do_nll_grad<double>((hipStream_t)stream, w, sc, x, Y, sr, theta, out, plan_host, plan_dev)
+                             : do_nll_grad<float>((hipStream_t)stream, w, sc, x, Y, sr, theta, out, plan_host, plan_dev);
+}
+
+int lcgp_plan_bytes(int dtype, int n, int q_local, int with_inverse, const lcgp_sched* sched, size_t* bytes) {
+    int rc = check_common(dtype, n, 1, 1, q_local);
+    if (rc) return rc;
+    if (!bytes) return bad("bytes is NULL");
+    lcgp_sched sc;
+    if ((rc = resolve_sched(sched, sc))) return rc;
+    *bytes = make_plan(dtype, n, q_local, with_inverse != 0, sc, nullptr);
+    return *bytes ? 0 : -1;
+}
+
+int lcgp_plan_build(int dtype, int n, int q_local, int with_inverse, const lcgp_sched* sched, void* plan, size_t bytes) {
+    int rc = check_common(dtype, n, 1, 1, q_local);
+    if (rc) return rc;
+    if (!plan) return bad("plan is NULL");
+    lcgp_sched sc;
+    if ((rc = resolve_sched(sched, sc))) return rc;
+    const size_t need = make_plan(dtype, n, q_local, with_inverse != 0, sc, nullptr);
+    if (!need) return -1;
+    if (bytes < need) return bad("plan buffer too small (lcgp_plan_bytes)");
+    return make_plan(dtype, n, q_local, with_inverse != 0, sc, plan) ? 0 : -1;
+}
+
+int lcgp_plan_info(const void* plan, int* nlaunch, int* nseg, int* ntasks, int* inverse_done) {
+    if (!plan) return bad("plan is NULL");
+    const PlanHeader* h = (const PlanHeader*)plan;
+    if (h->magic != PLAN_MAGIC || h->version != LCGP_VERSION) return bad("plan: not a plan of this library version");
+    if (nlaunch) *nlaunch = h->nlaunch;
+    if (nseg) *nseg = h->nseg;
+    if (ntasks) *ntasks = h->ntasks;
+    if (inverse_done) *inverse_done = h->inverse_done;
+    return 0;
 }
 
 int lcgp_pack_partial(void* stream, int d, int p, int q_local, int q_total, const int* comp, const double* theta,

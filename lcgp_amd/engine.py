@@ -44,7 +44,9 @@ class HotPathEngine:
         assert len(comp_ids) == self.q_local
         self.q_total = int(q_total) if q_total is not None else (max(comp_ids) + 1 if comp_ids else 1)
         assert all(0 <= k < self.q_total for k in comp_ids)
-        self.sched = None            # an _hip.Sched to override the launch schedule (tests / tools); None = defaults
+        self._sched_obj = None       # an _hip.Sched to override the launch schedule (tests / tools); None = defaults
+        self.use_plan = True         # the launch plan is built once per schedule (lcgp_plan_build) and passed with every call
+        self._plan_cache = {}        # with_inverse -> (host block, device copy)
         with torch.cuda.device(self.device):
             self.x = torch.as_tensor(x).to(self.device, self.tdtype).contiguous()
             self.Y = torch.as_tensor(Y).to(self.device, self.tdtype).contiguous()
@@ -80,8 +82,45 @@ class HotPathEngine:
     def _p(self, t):
         return C.c_void_p(0 if t is None else t.data_ptr())
 
+    @property
+    def sched(self):
+        return self._sched_obj
+
+    @sched.setter
+    def sched(self, s):
+        self._sched_obj = s
+        self._plan_cache = {}        # a plan carries the schedule it was built for
+
     def _sched(self):
-        return None if self.sched is None else C.byref(self.sched)
+        return None if self._sched_obj is None else C.byref(self._sched_obj)
+
+    def plan(self, with_inverse=True):
+        """(host pointer, device pointer) of the launch plan of the factorisation for the current schedule: planned ONCE
+        (lcgp_plan_build), the position-independent block kept in host memory and copied to the device once; both are
+        passed with every evaluation.  (None, None) with `use_plan = False`: the library then plans per call."""
+        if not self.use_plan:
+            return C.c_void_p(0), C.c_void_p(0)
+        key = bool(with_inverse)
+        if key not in self._plan_cache:
+            torch = self.torch
+            nbytes = C.c_size_t(0)
+            _hip.check(self.lib.lcgp_plan_bytes(self.dtype, self.n, self.q_local, int(key), self._sched(), C.byref(nbytes)),
+                       "lcgp_plan_bytes")
+            host = np.zeros(int(nbytes.value), dtype=np.uint8)
+            _hip.check(self.lib.lcgp_plan_build(self.dtype, self.n, self.q_local, int(key), self._sched(),
+                                                C.c_void_p(host.ctypes.data), nbytes), "lcgp_plan_build")
+            with torch.cuda.device(self.device):
+                dev = torch.from_numpy(host).to(self.device)
+            self._plan_cache[key] = (host, dev)
+        host, dev = self._plan_cache[key]
+        return C.c_void_p(host.ctypes.data), C.c_void_p(dev.data_ptr())
+
+    def plan_info(self, with_inverse=True):
+        """launches / segments / tasks / what the plan leaves behind the factorisation (lcgp_plan_info)"""
+        ph, _ = self.plan(with_inverse)
+        v = [C.c_int(0) for _ in range(4)]
+        _hip.check(self.lib.lcgp_plan_info(ph, *[C.byref(x) for x in v]), "lcgp_plan_info")
+        return dict(zip(("launches", "segments", "tasks", "inverse_done"), (x.value for x in v)))
 
     def upload_theta(self, theta_rows, guard=0.0):
         torch = self.torch
@@ -102,10 +141,11 @@ class HotPathEngine:
     def enqueue(self):
         """One pass of the hot path over the resident theta block (asynchronous)."""
         with self.torch.cuda.device(self.device):
+            ph, pd = self.plan(True)
             _hip.check(self.lib.lcgp_nll_grad(self._stream(), self.dtype, self.n, self.d, self.p, self.q_local,
                                               self._p(self.x), self._p(self.Y), self._p(self.sr),
                                               self._p(self.theta_dev), self._p(self.workspace), self._p(self.out_dev),
-                                              self._sched()),
+                                              self._sched(), ph, pd),
                        "lcgp_nll_grad")
 
     def evaluate(self, theta_rows):

@@ -462,6 +462,11 @@ class LCGP:
             return v[:-1]
 
         vec = reduced(eng)
+        if vec[1] < 0:
+            # not a property of the matrix: a wait inside the persistent factorisation launch expired (lcgp_sched.dag,
+            # include/lcgp_hip.h) and the launch drained with info = -1 on every component
+            raise RuntimeError('lcgp_amd: the persistent factorisation launch gave up a wait (info=%g); '
+                               'nothing was computed at these parameters' % vec[1])
         if (vec[1] != 0 or not np.isfinite(vec[0])) and self._dtype == 'float32' and self.float32_fallback:
             # The float32 factorisation broke down (I + D_k C_k has a condition number beyond single precision somewhere
             # along a line search; the reference is float64 only).  The point is evaluated again in float64 -- on every

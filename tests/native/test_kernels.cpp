@@ -183,7 +183,7 @@ static void run_case(int n, int d, int p, int q, bool rep, unsigned seed) {
     }
     report("kernel_build A", e_build, sizeof(T) == 8 ? 1e-14 : 1e-6);
 
-    LCHK(lcgp_potrf_logdet(nullptr, dtype, n, d, p, q, ws, dld, dinfo, nullptr));
+    LCHK(lcgp_potrf_logdet(nullptr, dtype, n, d, p, q, ws, dld, dinfo, nullptr, nullptr, nullptr));
     HIPCHK(hipDeviceSynchronize());
     vec hld(q);
     std::vector<int> hinfo(q);
@@ -230,7 +230,7 @@ static void run_case(int n, int d, int p, int q, bool rep, unsigned seed) {
 
     // whole path
     HIPCHK(hipMemset(ws, 0xff, wsb));
-    LCHK(lcgp_nll_grad(nullptr, dtype, n, d, p, q, dx, dY, srp, dtheta, ws, dout, nullptr));
+    LCHK(lcgp_nll_grad(nullptr, dtype, n, d, p, q, dx, dY, srp, dtheta, ws, dout, nullptr, nullptr, nullptr));
     HIPCHK(hipDeviceSynchronize());
     vec hout((size_t)q * ow);
     HIPCHK(hipMemcpy(hout.data(), dout, hout.size() * 8, hipMemcpyDeviceToHost));
@@ -280,6 +280,36 @@ static void run_case(int n, int d, int p, int q, bool rep, unsigned seed) {
     report("nll_grad NLL_k", e_nll, sizeof(T) == 8 ? 1e-10 : 5e-3);
     report("nll_grad kernel-param grads", e_g, sizeof(T) == 8 ? 1e-9 : 2e-2);
     report("nll_grad gsig", e_sig, sizeof(T) == 8 ? 1e-9 : 2e-2);
+
+    // the same call with a caller-owned plan: launch by launch (identical bits) and as the one persistent launch with
+    // dependencies inside it (sched.dag = 1: same bodies, same arithmetic per tile, so the same bits as well)
+    for (int dagmode = 0; dagmode < 2; ++dagmode) {
+        lcgp_sched sc;
+        LCHK(lcgp_sched_default(&sc));
+        sc.dag = dagmode;
+        size_t pb = 0;
+        LCHK(lcgp_plan_bytes(dtype, n, q, 1, &sc, &pb));
+        std::vector<char> plan(pb);
+        LCHK(lcgp_plan_build(dtype, n, q, 1, &sc, plan.data(), pb));
+        int nl = 0, ns = 0, nt = 0, inv = 0;
+        LCHK(lcgp_plan_info(plan.data(), &nl, &ns, &nt, &inv));
+        void* dplan;
+        HIPCHK(hipMalloc(&dplan, pb));
+        HIPCHK(hipMemcpy(dplan, plan.data(), pb, hipMemcpyHostToDevice));
+        HIPCHK(hipMemset(ws, 0xff, wsb));
+        HIPCHK(hipMemset(dout, 0, (size_t)q * ow * 8));
+        LCHK(lcgp_nll_grad(nullptr, dtype, n, d, p, q, dx, dY, srp, dtheta, ws, dout, nullptr, plan.data(), dplan));
+        HIPCHK(hipDeviceSynchronize());
+        vec hout2((size_t)q * ow);
+        HIPCHK(hipMemcpy(hout2.data(), dout, hout2.size() * 8, hipMemcpyDeviceToHost));
+        double e = 0;
+        for (size_t i = 0; i < hout2.size(); ++i) e = fmax(e, fabs(hout2[i] - hout[i]) / (1e-300 + fabs(hout[i])));
+        char what[96];
+        snprintf(what, sizeof(what), "%s (%d launches, %d segments, %d tasks) vs per-call plan",
+                 dagmode ? "persistent launch" : "caller-owned plan", nl, ns, nt);
+        report(what, e, 0.0);
+        HIPCHK(hipFree(dplan));
+    }
 
     // predict
     {

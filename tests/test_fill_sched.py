@@ -23,14 +23,27 @@ def dump_plan(tmp_path_factory):
     subprocess.run(['g++', '-std=c++17', '-O1', '-I', os.path.join(ROOT, 'lcgp_amd', 'csrc'), '-o', exe,
                     os.path.join(ROOT, 'tests', 'native', 'dump_plan.cpp')], check=True)
 
-    def run(nb, q, ob, syrk_small=2000, fill_leaf=248, fill_step=248, leaf_in_wide=1024, progressive=1, far_rides=1, with_dupd=1):
+    def run(nb, q, ob, syrk_small=2000, fill_leaf=248, fill_step=248, leaf_in_wide=1024, progressive=1, far_rides=1, with_dupd=1,
+            dag=0):
         out = subprocess.run([exe] + [str(v) for v in (nb, q, ob, syrk_small, fill_leaf, fill_step, leaf_in_wide, progressive,
-                                                       far_rides, with_dupd)],
+                                                       far_rides, with_dupd, dag)],
                              check=True, capture_output=True, text=True).stdout
         assert 'FAILED' not in out
         launches = []
+        segs = []
         for line in out.splitlines():
             f = line.split()
+            if f[0] == 'S':
+                v = [int(x) for x in f[1:27]]
+                keys = ('kind t0 ntasks per_comp k_off J pe c diag_end has_special n_trmm n_upd c_lo c_hi tiles128 with_leaf '
+                        'type nblk jt0 R0 R1 j0 j1 kb0 kb1 ndeps').split()
+                sg = dict(zip(keys, v))
+                sg['deps'] = [tuple(int(y) for y in x.split(':')) for x in f[27:]]
+                assert len(sg['deps']) == sg['ndeps']
+                sg['jobs'] = [dict(type=sg['type'], nblk=sg['nblk'], t0=sg['jt0'], R0=sg['R0'], R1=sg['R1'], j0=sg['j0'],
+                                   j1=sg['j1'], kb0=sg['kb0'], kb1=sg['kb1'])] if sg['kind'] == 4 else []
+                segs.append(sg)
+                continue
             v = [int(x) for x in f[1:]]
             if f[0] == 'L':
                 launches.append(dict(kind=v[0], J=v[1], pe=v[2], c=v[3], diag_end=v[4], has_special=v[5], n_trmm=v[6],
@@ -38,7 +51,7 @@ def dump_plan(tmp_path_factory):
             else:
                 launches[-1]['jobs'].append(dict(type=v[0], nblk=v[1], t0=v[2], R0=v[3], R1=v[4], j0=v[5], j1=v[6],
                                                  kb0=v[7], kb1=v[8]))
-        return launches
+        return (launches, segs) if dag else launches
     return run
 
 
@@ -55,11 +68,12 @@ class Replay:
             self.M[s, s] = self.A[s, s]
         self.W = np.full((n, n), np.nan)
         self.V = np.full((n, n), np.nan)
+        self.St = np.zeros((TS, TS))        # stands for the running log-determinant / status words of the component
         self.log = []
 
     # ---- block access with read / write logging (per work item) ----
     def begin_launch(self):
-        self.S = dict(M=self.M.copy(), W=self.W.copy(), V=self.V.copy())
+        self.S = dict(M=self.M.copy(), W=self.W.copy(), V=self.V.copy(), St=self.St.copy())
         self.writes = {}          # (buf, r, c) -> item
         self.reads = []           # (item, buf, r, c)
         self.item = 0
@@ -92,6 +106,7 @@ class Replay:
     # ---- kernels ----
     def leaf(self, blk_val, j):
         L = np.linalg.cholesky(blk_val)
+        self.wr('St', 0, 0, self.rd('St', 0, 1, 0, 1) + 1.0)
         self.wr('M', j, j, L)
         self.wr('W', j, j, np.tril(np.linalg.inv(L)))
         if j % 2 == 0 and j + 1 < self.nb:
@@ -233,6 +248,62 @@ class Replay:
                 assert np.allclose(self.V[s, s], Ai[s, s], rtol=0, atol=1e-9)
 
 
+class DagReplay(Replay):
+    """The same plan as the task graph of the persistent launch (fill_sched.h: DagBuilder).  Segments are executed in
+    sequence order, each on a snapshot of the state before it; every block a segment reads must have been last written
+    by a segment in the transitive closure of its declared dependencies (or be initial data), and every block it writes
+    must have had all its earlier readers and its last writer in that closure: with these two properties ANY execution
+    that respects the per-(segment, component) counters gives the result of the sequential one."""
+
+    def run_dag(self, segs):
+        nseg = len(segs)
+        clo = []
+        for i, sg in enumerate(segs):
+            c = set()
+            for d, need in sg['deps']:
+                assert 0 <= d < i, 'dependencies point backwards in the sequence'
+                assert need == segs[d]['per_comp']
+                c.add(d)
+                c |= clo[d]
+            clo.append(c)
+        last_w = {}          # block -> segment
+        readers = {}         # block -> segments that read it since its last write
+        t_expect = 0
+        for i, sg in enumerate(segs):
+            assert sg['t0'] == t_expect and sg['ntasks'] == sg['per_comp'] * self.q
+            t_expect += sg['ntasks']
+            self.begin_launch()
+            if sg['kind'] == 1:
+                self.run_leaf(sg)
+            elif sg['kind'] == 2:
+                self.run_step(sg)
+            elif sg['kind'] == 3:
+                self.run_trail(sg)
+            else:
+                self.run_jobs(sg)
+            self.end_launch()
+            nitems = self.item
+            if sg['kind'] == 3 and sg['tiles128']:
+                # the kernel works on 128x128 tiles there (4 blocks, 3 on the diagonal, per task): same blocks, fewer tasks
+                nitems = sg['per_comp']
+            if sg['kind'] != 4 or sg['type'] < 5:     # (a task of a block-inverse level may fall outside the matrix)
+                assert nitems == sg['per_comp'], (i, sg, nitems)
+            rset = {(b, r, c) for _, b, r, c in self.reads}
+            for key in rset:
+                w = last_w.get(key)
+                assert w is None or w == i or w in clo[i], 'segment %d reads %s written by %d: not a dependency' % (i, key, w)
+            for key in self.writes:
+                for o in [last_w.get(key)] + sorted(readers.get(key, ())):
+                    assert o is None or o == i or o in clo[i], 'segment %d writes %s last touched by %d: not a dependency' % (i, key, o)
+            for key in self.writes:
+                last_w[key] = i
+                readers[key] = set()
+            for key in rset:
+                if key not in self.writes:
+                    readers.setdefault(key, set()).add(i)
+        return max(sg['ndeps'] for sg in segs)
+
+
 CASES = [
     # nb, q, ob, kwargs
     (64, 1, 4, {}),                               # the headline size, one component per GPU
@@ -290,3 +361,35 @@ def test_filler_capacity_is_respected(dump_plan):
             if l['kind'] in (1, 2):
                 assert l['nblk'] <= 248
                 assert len(l['jobs']) <= 6
+
+
+@pytest.mark.parametrize('nb,q,ob,kw', CASES + [(14, 2, 6, {}), (16, 1, 3, {})])
+@pytest.mark.parametrize('progressive', [0, 1])
+def test_task_graph_dependencies_cover_every_block_hazard(dump_plan, nb, q, ob, kw, progressive):
+    if progressive and (ob & (ob - 1)):
+        pytest.skip('the progressive inverse needs a power-of-two panel')
+    launches, segs = dump_plan(nb, q, ob, progressive=progressive, dag=1, **kw)
+    r = DagReplay(nb, q, seed=5 * nb + q)
+    maxdep = r.run_dag(segs)
+    assert maxdep <= 8
+    r.check(inverse=bool(progressive))
+    # the graph holds exactly the work of the launch list
+    assert sum(sg['ntasks'] for sg in segs if sg['kind'] == 4) == sum(jb['nblk'] for l in launches for jb in l['jobs'])
+
+
+def test_task_graph_mutations_are_caught(dump_plan):
+    """dropping any single declared dependency of the headline graph must trip the hazard check (the lists are minimal)"""
+    launches, segs = dump_plan(16, 2, 4, progressive=1, dag=1)
+    caught = total = 0
+    for i, sg in enumerate(segs):
+        for j in range(sg['ndeps']):
+            import copy
+            mut = copy.deepcopy(segs)
+            del mut[i]['deps'][j]
+            mut[i]['ndeps'] -= 1
+            total += 1
+            try:
+                DagReplay(16, 2, seed=1).run_dag(mut)
+            except AssertionError:
+                caught += 1
+    assert total > 20 and caught == total, (caught, total)
