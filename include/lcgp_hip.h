@@ -83,10 +83,19 @@ typedef struct lcgp_sched {
                                has at most this many 64-blocks per side (48); beyond, only L^-1 is, and A^-1 takes the one
                                launch of lcgp_lauum after the factorisation (0 = always that) */
     int dag;                /* with a plan (lcgp_plan_build): 1 = the factorisation runs as ONE persistent launch whose tasks wait
-                               for each other through per-(segment, component) counters in the workspace, 0 = launch by launch */
+                               for each other through per-(segment, component) counters in the workspace, 0 = launch by launch;
+                               2 = the persistent launch with its own task order: every trailing update cut into the block
+                               columns of the next panel (near) and the rest (far), the far part in chunks that alternate
+                               with the next panel's chain (no inverse behind the chain in this order) */
     int dag_spin_limit;     /* polls of one wait inside that launch before it gives up: the failure word is set, every later
                                wait returns at once, the launch drains and every component reports info = -1
                                (0 = 2,000,000 polls, about two seconds; tests set 1 to see the failure path) */
+    int dag_flags;          /* protocol variants of the persistent launch, for measurement and diagnosis (0 = the product):
+                               1 = a task always waits and acquires (no "this workgroup has already seen these dependencies"),
+                               2 = an agent-scope release fence (buffer_wbl2) in front of every publication,
+                               4 = system-scope instead of agent-scope acquire,
+                               8 = plain result stores and a release fence instead of write-through stores,
+                               16 = the next task is taken after the publication instead of before the drain */
 } lcgp_sched;
 int lcgp_sched_default(lcgp_sched* sched /*host out*/);
 

@@ -11,7 +11,8 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_HERE)
-LIB_PATH = os.path.join(_HERE, "liblcgp_hip.so")
+# (LCGP_HIP_LIB: tools only -- e.g. the stamped build of `make trace`; tests and the package use the in-tree library)
+LIB_PATH = os.environ.get("LCGP_HIP_LIB") or os.path.join(_HERE, "liblcgp_hip.so")
 SRC_PATH = os.path.join(_HERE, "csrc", "lcgp_hip.hip")
 HDR_PATH = os.path.join(_ROOT, "include", "lcgp_hip.h")
 SCHED_PATH = os.path.join(_HERE, "csrc", "fill_sched.h")
@@ -24,7 +25,7 @@ class Sched(C.Structure):
     _fields_ = [("outer_blocks", C.c_int), ("syrk_small_tiles", C.c_int), ("trtri_small_tiles", C.c_int),
                 ("lauum_small_tiles", C.c_int), ("trtri_level_small", C.c_int), ("fill_leaf", C.c_int),
                 ("fill_step", C.c_int), ("leaf_in_wide", C.c_int), ("progressive_tiles", C.c_int), ("progressive_far", C.c_int), ("progressive_lauum", C.c_int),
-                ("dag", C.c_int), ("dag_spin_limit", C.c_int)]
+                ("dag", C.c_int), ("dag_spin_limit", C.c_int), ("dag_flags", C.c_int)]
 
 
 # every symbol include/lcgp_hip.h declares: name -> (restype, argtypes)

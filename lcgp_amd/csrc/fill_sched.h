@@ -271,6 +271,8 @@ struct PlanParams {
     bool far_rides;          // the far columns of a trailing update ride on the next panel's chain (else: one wide launch)
     bool with_dupd = true;   // progressive: A^-1 = W^T W is accumulated behind the chain too (else only L^-1 is; the caller
                              // then forms A^-1 in one launch after the factorisation)
+    bool interleaved = false; // order for the persistent launch (Planner::run_interleaved): near / far trailing updates,
+                              // the far part cut into chunks that alternate with the next panel's chain
 };
 
 enum LaunchKind {
@@ -285,6 +287,7 @@ struct Launch {
     int J = 0, pe = 0, c = 0;
     int diag_end = 0, has_special = 0, n_trmm = 0, n_upd = 0;       // L_STEP
     int c_lo = 0, c_hi = 0, tiles128 = 0, with_leaf = 0;            // L_TRAIL
+    int t_first = 0, t_count = 0;                                   // L_TRAIL: a sub-range of its tiles (t_count = 0: all of them)
     FillSet fs;                                                     // job descriptors (base pointers are set by the executor)
 };
 
@@ -297,7 +300,74 @@ class Planner {
     std::vector<Launch> launches;
     bool inverse_planned = false;
 
+    // Order for the persistent launch (dag_kernel takes the tasks of all segments in sequence): the trailing update of
+    // panel P is cut into its NEAR part -- the block columns of panel P + 1, all the next chain reads or writes -- and its
+    // FAR part, and the far part into chunks that alternate with the launches of the chain of panel P + 1:
+    //     ... near(P) | leaf | far(P) 1/5 | step | far(P) 2/5 | step | ... | near(P+1) | ...
+    // A chain task then never waits for far tiles (the dependencies are derived per segment from the blocks it touches),
+    // the workgroups that are not on the chain always find update tiles to run, and no update ends in a half-empty round
+    // of tiles because nothing ends at all: the next segment's tiles follow.  Executed launch by launch the list is valid
+    // too (it is what tests/test_fill_sched.py replays), only slow.
+    void run_interleaved() {
+        const int nb = pp.nb, ob = pp.ob, q = pp.q;
+        const bool t128 = (ob & 1) == 0;
+        struct Far { int J, pe, c_lo, tiles128; long ntiles; } far = {0, 0, 0, 0, 0};
+        for (int J = 0; J < nb; J += ob) {
+            const int pe = J + ob < nb ? J + ob : nb;
+            // the chain of this panel, alternating with the chunks of the previous panel's far update
+            std::vector<Launch> chain;
+            {
+                Launch l;
+                l.kind = L_LEAF; l.J = J; l.pe = pe;
+                l.fs.njobs = 0; l.fs.nblk = 0;
+                chain.push_back(l);
+            }
+            for (int c = J; c < pe && c + 1 < nb; ++c) {
+                Launch l;
+                l.kind = L_STEP; l.J = J; l.pe = pe; l.c = c;
+                l.diag_end = pe;
+                l.has_special = c + 1 < pe ? 1 : 0;
+                l.n_trmm = nb - 1 - c;
+                l.n_upd = (c > J && c + 1 < pe) ? nb - (c + 1) - 1 : 0;
+                l.fs.njobs = 0; l.fs.nblk = 0;
+                chain.push_back(l);
+            }
+            const int nch = (int)chain.size();
+            long given = 0;
+            for (int i = 0; i < nch; ++i) {
+                launches.push_back(chain[i]);
+                if (far.ntiles > 0) {
+                    const long upto = far.ntiles * (i + 1) / nch;
+                    if (upto > given) {
+                        Launch l;
+                        l.kind = L_TRAIL; l.J = far.J; l.pe = far.pe; l.c_lo = far.c_lo; l.c_hi = nb; l.tiles128 = far.tiles128;
+                        l.with_leaf = 0; l.t_first = (int)given; l.t_count = (int)(upto - given);
+                        l.fs.njobs = 0; l.fs.nblk = 0;
+                        launches.push_back(l);
+                        given = upto;
+                    }
+                }
+            }
+            far.ntiles = 0;
+            if (pe >= nb) break;
+            // near part: the columns of the next panel; far part: everything to the right of them
+            const int ne = pe + ob < nb ? pe + ob : nb;
+            const bool w128 = t128 && (long long)q * trapezoid_tiles(nb / 2, pe / 2, nb / 2) >= pp.syrk_small_tiles;
+            {
+                Launch l;
+                l.kind = L_TRAIL; l.J = J; l.pe = pe; l.c_lo = pe; l.c_hi = ne; l.tiles128 = w128 ? 1 : 0; l.with_leaf = 0;
+                l.fs.njobs = 0; l.fs.nblk = 0;
+                launches.push_back(l);
+            }
+            if (ne < nb) {
+                far.J = J; far.pe = pe; far.c_lo = ne; far.tiles128 = w128 ? 1 : 0;
+                far.ntiles = w128 ? trapezoid_tiles(nb / 2, ne / 2, nb / 2) : trapezoid_tiles(nb, ne, nb);
+            }
+        }
+    }
+
     void run() {
+        if (pp.interleaved) { run_interleaved(); return; }
         const int nb = pp.nb, ob = pp.ob, q = pp.q;
         const bool t128 = (ob & 1) == 0;
         inverse_planned = pp.progressive;
@@ -512,7 +582,7 @@ class Planner {
 // write-after-write and write-after-read alike) and reduced transitively.  tests/test_fill_sched.py replays the graph
 // on numpy matrices and checks every block-level hazard against the declared lists.
 // ---------------------------------------------------------------------------------------------------
-constexpr int DAG_MAXDEP = 8;
+constexpr int DAG_MAXDEP = 16;
 
 enum SegKind { S_LEAF = 1, S_STEP = 2, S_TRAIL = 3, S_FILL = 4 };
 
@@ -526,6 +596,7 @@ struct DagSeg {
     int need[DAG_MAXDEP];    // their per_comp
     int J, pe, c, diag_end, has_special, n_trmm, n_upd;      // S_LEAF (J) / S_STEP
     int c_lo, c_hi, tiles128, with_leaf;                     // S_TRAIL (+ J, pe)
+    int t_first, t_count;                                    // S_TRAIL: a sub-range of the update's tiles (t_count = 0: all)
     FillJob job;                                             // S_FILL
 };
 
@@ -567,15 +638,36 @@ class DagBuilder {
             } else if (l.kind == L_TRAIL) {
                 DagSeg s = blank(S_TRAIL);
                 s.J = l.J; s.pe = l.pe; s.c_lo = l.c_lo; s.c_hi = l.c_hi; s.tiles128 = l.tiles128; s.with_leaf = l.with_leaf;
-                const int nt = l.tiles128 ? trapezoid_tiles(nb / 2, l.c_lo / 2, l.c_hi / 2) + (l.with_leaf ? 1 : 0)
-                                          : trapezoid_tiles(nb, l.c_lo, l.c_hi);
+                std::vector<Access> a;
+                int nt;
+                if (l.t_count > 0) {
+                    // a sub-range of the tiles (column-major over the tile columns from c_lo on): the columns it touches
+                    const int u = l.tiles128 ? 2 : 1, nbt = nb / u;
+                    int c = l.c_lo / u;
+                    long t = l.t_first;
+                    while (t >= nbt - c) { t -= nbt - c; ++c; }
+                    long left = l.t_count;
+                    while (left > 0) {
+                        const long in_col = nbt - c - t;
+                        const long take = left < in_col ? left : in_col;
+                        const int ra = c + (int)t, rb = ra + (int)take;
+                        a.push_back({BUF_M, ra * u, rb * u, c * u, (c + 1) * u, true});
+                        a.push_back({BUF_M, ra * u, rb * u, l.J, l.pe, false});
+                        a.push_back({BUF_M, c * u, (c + 1) * u, l.J, l.pe, false});
+                        left -= take; t = 0; ++c;
+                    }
+                    nt = l.t_count;
+                    s.t_first = l.t_first; s.t_count = l.t_count;
+                } else {
+                    nt = l.tiles128 ? trapezoid_tiles(nb / 2, l.c_lo / 2, l.c_hi / 2) + (l.with_leaf ? 1 : 0)
+                                    : trapezoid_tiles(nb, l.c_lo, l.c_hi);
+                    a.push_back({BUF_M, l.c_lo, nb, l.J, l.pe, false});
+                    a.push_back({BUF_M, l.c_lo, nb, l.c_lo, l.c_hi, true});
+                    if (l.with_leaf) leaf_access(a, l.c_lo);
+                }
                 s.per_comp = nt;
                 s.ntasks = nt * q;
                 s.k_off = l.with_leaf ? q : 0;
-                std::vector<Access> a;
-                a.push_back({BUF_M, l.c_lo, nb, l.J, l.pe, false});
-                a.push_back({BUF_M, l.c_lo, nb, l.c_lo, l.c_hi, true});
-                if (l.with_leaf) leaf_access(a, l.c_lo);
                 push(s, a);
             }
             for (int i = 0; i < l.fs.njobs; ++i) {
@@ -600,7 +692,7 @@ class DagBuilder {
         s.kind = kind; s.t0 = 0; s.ntasks = 0; s.per_comp = 0; s.k_off = 0; s.ndeps = 0;
         for (int i = 0; i < DAG_MAXDEP; ++i) { s.dep[i] = -1; s.need[i] = 0; }
         s.J = s.pe = s.c = s.diag_end = s.has_special = s.n_trmm = s.n_upd = 0;
-        s.c_lo = s.c_hi = s.tiles128 = s.with_leaf = 0;
+        s.c_lo = s.c_hi = s.tiles128 = s.with_leaf = 0; s.t_first = s.t_count = 0;
         s.job.type = FILL_NONE; s.job.nblk = 0; s.job.t0 = 0; s.job.R0 = s.job.R1 = s.job.j0 = s.job.j1 = 0;
         s.job.kb0 = s.job.kb1 = 0;
         return s;

@@ -56,7 +56,7 @@ struct Ws {
     size_t esz;
     size_t mat;          // elements per matrix
     char* base;
-    size_t off_M, off_W, off_V, off_b, off_z, off_part, off_cpart, off_c, off_logdet, off_info, off_dag, total;
+    size_t off_M, off_W, off_V, off_b, off_z, off_part, off_cpart, off_c, off_logdet, off_info, off_dag, off_trace, total;
     int ntile_lower;
 };
 
@@ -65,6 +65,7 @@ inline size_t align256(size_t x) { return (x + 255) & ~size_t(255); }
 // control words of the persistent factorisation launch (dag_kernel): 16 ints + one counter per (segment, component); the
 // bound on the segments of a plan follows from fill_sched.h (launches <= 8 nb + 16, at most 1 + NJ segments per launch)
 inline size_t dag_ctl_ints(int nb, int q) { return 16 + (size_t)(56 * nb + 112) * q; }
+constexpr int DAG_TRACE_CAP = 1 << 18;
 
 inline Ws carve(int dtype, int n, int d, int p, int q, void* base) {
     Ws w;
@@ -89,6 +90,10 @@ inline Ws carve(int dtype, int n, int d, int p, int q, void* base) {
     w.off_logdet = o; o = align256(o + (size_t)q * sizeof(double));
     w.off_info = o; o = align256(o + (size_t)q * sizeof(int));
     w.off_dag = o; o = align256(o + dag_ctl_ints(w.nb, q) * sizeof(int));
+    w.off_trace = o;
+#ifdef LCGP_DAG_TRACE
+    o = align256(o + (size_t)DAG_TRACE_CAP * 32);       // tool build: four time stamps per task at the END of the workspace
+#endif
     w.total = o;
     return w;
 }
@@ -121,6 +126,15 @@ __device__ __forceinline__ int body_tid() {
     asm volatile("" : "+v"(t));
     __builtin_assume(t >= 0 && t < 1024);
     return t;
+}
+// Store of a result element.  WT (the persistent launch): write-through -- the element leaves for memory at once (sc1), so
+// that publishing a finished tile to other workgroups needs no write-back of the whole L2 (buffer_wbl2) behind it: every
+// storing wave drains its stores, the workgroup meets at a barrier, one lane adds to the counter (MI355X_MICROARCH.md,
+// inter-workgroup visibility: write-through payload + drained flag; the consumer side keeps its agent-scope acquire).
+template <bool WT, typename T>
+__device__ __forceinline__ void gstore(T* p, T v) {
+    if constexpr (WT) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else *p = v;
 }
 // the same for a wave-uniform value that comes from the kernel arguments
 __device__ __forceinline__ int opaque_s(int v) {
@@ -512,26 +526,26 @@ __device__ __forceinline__ void leaf_inverse_w(double (*w)[LEAF_LDT], const d4& 
 // The results leave for memory as they become final, on waves that would otherwise wait at the panel's barrier: L panel
 // kb-1 and row block kb-2 of the inverse during panel kb (and the zero quadrant beside W during panel 0), so that only
 // the last panel, the last two row blocks and the log-determinant are left after the chain.
-template <typename T>
+template <typename T, bool WT>
 __device__ __forceinline__ void leaf_store_l_panel(T* __restrict__ Mb, int npad, double (*lt)[LEAF_LDT], int pb, int lane) {
     const int col = pb * 16 + (lane & 15);
 #pragma unroll
     for (int m = 0; m < 16; ++m) {
         const int i = (lane >> 4) + 4 * m;
-        Mb[(size_t)i * npad + col] = (T)lt[col][i];
+        gstore<WT>(Mb + (size_t)i * npad + col, (T)lt[col][i]);
     }
 }
 
-template <typename T>
+template <typename T, bool WT>
 __device__ __forceinline__ void leaf_store_w_rows(T* __restrict__ Wb, int npad, double (*w)[LEAF_LDT], int a, int lane) {
 #pragma unroll
     for (int m = 0; m < 16; ++m) {
         const int i = a * 16 + m;
-        Wb[(size_t)i * npad + lane] = (T)(lane <= i ? w[i][lane] : 0.0);
+        gstore<WT>(Wb + (size_t)i * npad + lane, (T)(lane <= i ? w[i][lane] : 0.0));
     }
 }
 
-template <typename T, bool FROM_LDS>
+template <typename T, bool FROM_LDS, bool WT>
 __device__ __forceinline__ void leaf_factor_invert(T* __restrict__ Mb, T* __restrict__ Wb, int npad, double (*lt)[LEAF_LDT],
                                                    double (*w)[LEAF_LDT], double* scratch, double* dinv, double* pivs,
                                                    int* bad, int jb) {
@@ -591,11 +605,11 @@ __device__ __forceinline__ void leaf_factor_invert(T* __restrict__ Mb, T* __rest
         } else if (kb == 0) {
             // the 128x128 tile kernels read whole diagonal 128-blocks of W: keep the quadrant above this block zero
             if ((jb & 1) == 0)
-                for (int i = wv - 1; i < TS; i += 3) Wb[(size_t)i * npad + TS + lane] = (T)0;
+                for (int i = wv - 1; i < TS; i += 3) gstore<WT>(Wb + (size_t)i * npad + TS + lane, (T)0);
         } else if (wv == ((kb + 1) & 3)) {
-            leaf_store_l_panel<T>(Mb, npad, lt, kb - 1, lane);
+            leaf_store_l_panel<T, WT>(Mb, npad, lt, kb - 1, lane);
         } else if (kb >= 2 && wv == ((kb + 2) & 3)) {
-            leaf_store_w_rows<T>(Wb, npad, w, kb - 2, lane);
+            leaf_store_w_rows<T, WT>(Wb, npad, w, kb - 2, lane);
         }
         __syncthreads();
         if (wv > kb) {
@@ -616,13 +630,13 @@ __device__ __forceinline__ void leaf_factor_invert(T* __restrict__ Mb, T* __rest
     else tacc = leaf_inverse_t(lt, w, 3, wv, lane);
     __syncthreads();
     if (wv < 3) leaf_inverse_w(w, tacc, 3, wv, lane);
-    else leaf_store_l_panel<T>(Mb, npad, lt, 3, lane);
+    else leaf_store_l_panel<T, WT>(Mb, npad, lt, 3, lane);
     __syncthreads();
-    if (wv == 1) leaf_store_w_rows<T>(Wb, npad, w, 2, lane);
-    else if (wv == 2) leaf_store_w_rows<T>(Wb, npad, w, 3, lane);
+    if (wv == 1) leaf_store_w_rows<T, WT>(Wb, npad, w, 2, lane);
+    else if (wv == 2) leaf_store_w_rows<T, WT>(Wb, npad, w, 3, lane);
 }
 
-template <typename T, bool FROM_LDS = false>
+template <typename T, bool FROM_LDS = false, bool WT = false>
 __device__ __forceinline__ void leaf_body(unsigned char* lds, int k, T* __restrict__ M, T* __restrict__ W, size_t mat,
                                           int npad, int jb, double* __restrict__ logdet, int* __restrict__ info) {
     double (*lt)[LEAF_LDT] = (double (*)[LEAF_LDT])lds;                   // lt[col][row] = L[row][col]
@@ -638,14 +652,14 @@ __device__ __forceinline__ void leaf_body(unsigned char* lds, int k, T* __restri
     double ld_prev = 0.0;
     int info_prev = 0;
     if (tid == 0) { ld_prev = logdet[k]; info_prev = info[k]; }
-    leaf_factor_invert<T, FROM_LDS>(Mb, Wb, npad, lt, w, scratch, dinv, pivs, bad, jb);
+    leaf_factor_invert<T, FROM_LDS, WT>(Mb, Wb, npad, lt, w, scratch, dinv, pivs, bad, jb);
     if (tid < TS) {   // wave 0 (the other waves are storing the last rows): 1/2 sum log(pivot)
         double lg = 0.5 * log(pivs[tid]);
         for (int off = 32; off > 0; off >>= 1) lg += __shfl_xor(lg, off);
         if (tid == 0) {
-            logdet[k] = ld_prev + lg;
+            gstore<WT>(logdet + k, ld_prev + lg);
             const int fb = bad[0] ? bad[0] : bad[1] ? bad[1] : bad[2] ? bad[2] : bad[3];
-            if (fb && info_prev == 0) info[k] = fb;
+            if (fb && info_prev == 0) gstore<WT>(info + k, fb);
         }
     }
 }
@@ -762,7 +776,7 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 //   TM = 128, NW = 8: 32x64 per wave (2x4 accumulators), 2 workgroups per CU = 4 waves per SIMD, half the
 //                     operand traffic per flop of the 64-tile
 // All tile coordinates (g.nb, g.p0..p3) are in units of TM.
-template <typename T, int OP, int TM, int NW>
+template <typename T, int OP, int TM, int NW, bool WT = false>
 __device__ __forceinline__ void gemm_body(const GemmArgs& g, const int lin /*block index within this descriptor*/,
                                           unsigned char* lds) {
     constexpr int LA = (OP == OP_LAUUM) ? KM : MK;
@@ -994,11 +1008,11 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, const int lin /*blo
                     if (g.skipq && bid + g.t0 == 0 && row < TS && col < TS) continue;
                 }
                 if constexpr (PRELOAD_C) {
-                    *dst = acc[mi][ni][e];
+                    gstore<WT>(dst, (T)acc[mi][ni][e]);
                 } else {
                     double v = alpha * (double)acc[mi][ni][e];
                     if (accumulate) v += (double)*dst;
-                    *dst = (T)v;
+                    gstore<WT>(dst, (T)v);
                 }
             }
     if constexpr (OP == OP_LAUUM && TM == 128) {
@@ -1072,7 +1086,7 @@ __global__ __launch_bounds__(NW * 64, TM == 128 ? (NW == 8 ? 4 : 2) : 4) void ti
 using lcgp_fill::FillJob;
 using lcgp_fill::FillSet;
 
-template <typename T, int LA, int LB, bool NEG>
+template <typename T, int LA, int LB, bool NEG, bool WT = false>
 __device__ __forceinline__ void rect_tile(const T* __restrict__ A0, int ldA, const T* __restrict__ B0, int ldB,
                                           T* __restrict__ Ct, int ldC, int nst, bool first, unsigned char* lds) {
     constexpr int TMR = 128, TNC = 64, NT = 256;
@@ -1163,11 +1177,11 @@ __device__ __forceinline__ void rect_tile(const T* __restrict__ A0, int ldA, con
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int e = 0; e < 4; ++e)
-                Ct[(size_t)(wm0 + i * 16 + Mfma<T>::row(lane, e)) * ldC + wn0 + j * 16 + (lane & 15)] = acc[i][j][e];
+                gstore<WT>(Ct + (size_t)(wm0 + i * 16 + Mfma<T>::row(lane, e)) * ldC + wn0 + j * 16 + (lane & 15), (T)acc[i][j][e]);
 }
 
 // One block of a filler set: block b of the launch's filler range -> (job, component, tile) -> operands (fill_sched.h).
-template <typename T>
+template <typename T, bool WT = false>
 __device__ __forceinline__ void fill_dispatch(const FillSet& fs, int b, unsigned char* lds) {
     int ji = 0;
     while (ji + 1 < fs.njobs && b >= fs.job[ji].nblk) { b -= fs.job[ji].nblk; ++ji; }
@@ -1179,10 +1193,10 @@ __device__ __forceinline__ void fill_dispatch(const FillSet& fs, int b, unsigned
         g.p0 = jb.R0; g.p1 = jb.R1; g.p2 = jb.j0; g.p3 = 0; g.q = fs.q; g.t0 = 0; g.skipq = 1;
         if (jb.type == lcgp_fill::FILL_TRI_T) {
             g.A = fs.M; g.B = fs.W; g.C = fs.V;
-            gemm_body<T, OP_TRTRI_T, 64, 4>(g, b + jb.t0 * fs.q, lds);       // (a job may be split over launches)
+            gemm_body<T, OP_TRTRI_T, 64, 4, WT>(g, b + jb.t0 * fs.q, lds);       // (a job may be split over launches)
         } else {
             g.A = fs.W; g.B = fs.V; g.C = fs.W;
-            gemm_body<T, OP_TRTRI_W, 64, 4>(g, b + jb.t0 * fs.q, lds);
+            gemm_body<T, OP_TRTRI_W, 64, 4, WT>(g, b + jb.t0 * fs.q, lds);
         }
         return;
     }
@@ -1197,14 +1211,14 @@ __device__ __forceinline__ void fill_dispatch(const FillSet& fs, int b, unsigned
         int j = jb.j0;
         while (t >= jb.R1 - (j >> 1)) { t -= jb.R1 - (j >> 1); ++j; }
         const int R = (j >> 1) + t;
-        rect_tile<T, MK, MK, true>(M + (size_t)R * 128 * ld + (size_t)kb0 * TS, ld, M + (size_t)j * TS * ld + (size_t)kb0 * TS, ld,
+        rect_tile<T, MK, MK, true, WT>(M + (size_t)R * 128 * ld + (size_t)kb0 * TS, ld, M + (size_t)j * TS * ld + (size_t)kb0 * TS, ld,
                                    M + (size_t)R * 128 * ld + (size_t)j * TS, ld, (kb1 - kb0) * (TS / KT), false, lds);
     } else if (jb.type == lcgp_fill::FILL_BROW) {
         // W[R, j] = -W[R, kb0 .. ] V[kb0 .., j]: row block R of the panel's block inverse (lower triangular: k < 2R + 2)
         const int nc = jb.j1 - jb.j0;
         const int R = jb.R0 + t / nc, j = jb.j0 + t % nc;
         const int ke = kb1 < 2 * R + 2 ? kb1 : 2 * R + 2;
-        rect_tile<T, MK, KM, true>(W + (size_t)R * 128 * ld + (size_t)kb0 * TS, ld, V + (size_t)kb0 * TS * ld + (size_t)j * TS, ld,
+        rect_tile<T, MK, KM, true, WT>(W + (size_t)R * 128 * ld + (size_t)kb0 * TS, ld, V + (size_t)kb0 * TS * ld + (size_t)j * TS, ld,
                                    W + (size_t)R * 128 * ld + (size_t)j * TS, ld, (ke - kb0) * (TS / KT), true, lds);
     } else if (jb.type == lcgp_fill::FILL_CUPD) {
         // V[R, j] (+)= M[R, kb0 ..] W[kb0 .., j]; a column inside the panel starts at its own 128-aligned block row (zeros
@@ -1213,7 +1227,7 @@ __device__ __forceinline__ void fill_dispatch(const FillSet& fs, int b, unsigned
         const int R = jb.R0 + t / nc, j = jb.j0 + t % nc;
         const bool own = j >= kb0;
         const int ks = kb0 + (own ? ((j - kb0) & ~1) : 0);
-        rect_tile<T, MK, KM, false>(M + (size_t)R * 128 * ld + (size_t)ks * TS, ld, W + (size_t)ks * TS * ld + (size_t)j * TS, ld,
+        rect_tile<T, MK, KM, false, WT>(M + (size_t)R * 128 * ld + (size_t)ks * TS, ld, W + (size_t)ks * TS * ld + (size_t)j * TS, ld,
                                     V + (size_t)R * 128 * ld + (size_t)j * TS, ld, (kb1 - ks) * (TS / KT), own, lds);
     } else {
         // FILL_DUPD: V[R, j] (+)= W[kb0 .., R]^T W[kb0 .., j]; a row block inside (or below) the K range starts at its own
@@ -1224,7 +1238,7 @@ __device__ __forceinline__ void fill_dispatch(const FillSet& fs, int b, unsigned
         const int j = t - R * (R + 1);
         const bool own = 2 * R >= kb0;
         const int ks = own ? 2 * R : kb0;
-        rect_tile<T, KM, KM, false>(W + (size_t)ks * TS * ld + (size_t)R * 128, ld, W + (size_t)ks * TS * ld + (size_t)j * TS, ld,
+        rect_tile<T, KM, KM, false, WT>(W + (size_t)ks * TS * ld + (size_t)R * 128, ld, W + (size_t)ks * TS * ld + (size_t)j * TS, ld,
                                     V + (size_t)R * 128 * ld + (size_t)j * TS, ld, (kb1 - ks) * (TS / KT), own, lds);
     }
 }
@@ -1303,6 +1317,7 @@ struct Tile64 {          // 64x64 tile on 256 threads: wave (wm, wn) owns a 32x3
 #pragma unroll
                 for (int e = 0; e < 4; ++e) acc[i][j][e] = 0;
     }
+    template <bool WT>
     static __device__ __forceinline__ void store(const acc_t (&acc)[2][2], T* Ct, int ld, int lane, int wm0, int wn0) {
 #pragma unroll
         for (int i = 0; i < 2; ++i)
@@ -1310,7 +1325,7 @@ struct Tile64 {          // 64x64 tile on 256 threads: wave (wm, wn) owns a 32x3
             for (int j = 0; j < 2; ++j)
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
-                    Ct[(size_t)(wm0 + i * 16 + Mfma<T>::row(lane, e)) * ld + wn0 + j * 16 + (lane & 15)] = acc[i][j][e];
+                    gstore<WT>(Ct + (size_t)(wm0 + i * 16 + Mfma<T>::row(lane, e)) * ld + wn0 + j * 16 + (lane & 15), (T)acc[i][j][e]);
     }
     // One 64x64 operand (element (m, k) at P[m * ld + k]) into registers: all four K stages at once = one memory latency
     static __device__ __forceinline__ void fetch(T (&p)[SPT][EPT], const T* P, int ld, int tid) {
@@ -1422,7 +1437,7 @@ struct Tile64 {          // 64x64 tile on 256 threads: wave (wm, wn) owns a 32x3
     }
 };
 
-template <typename T>
+template <typename T, bool WT = false>
 __device__ __forceinline__ void chain_step_body(const StepArgs& a, int b, unsigned char* lds) {
     typedef Tile64<T> TL;
     const int tid = body_tid(), lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1432,7 +1447,7 @@ __device__ __forceinline__ void chain_step_body(const StepArgs& a, int b, unsign
     const int nspecial = a.has_special * a.q;
     int t = -1, k = 0;
     if (b < nspecial) { t = 0; k = b; }
-    else if (b < nspecial + a.fs.nblk) { fill_dispatch<T>(a.fs, b - nspecial, lds); return; }
+    else if (b < nspecial + a.fs.nblk) { fill_dispatch<T, WT>(a.fs, b - nspecial, lds); return; }
     else {
         b -= nspecial + a.fs.nblk;
         if (b < (a.n_trmm - a.has_special) * a.q) { k = b % a.q; t = b / a.q + a.has_special; }
@@ -1462,7 +1477,7 @@ __device__ __forceinline__ void chain_step_body(const StepArgs& a, int b, unsign
         TL::to_operand(acc, F, lane, wm0, wn0);
         TL::zero(acc);
         TL::template mma_a_lds<false>(acc, F, pw, Bst, tid, lane, wm0, wn0);
-        TL::store(acc, Ct, ld, lane, wm0, wn0);         // L[r, c]
+        TL::template store<WT>(acc, Ct, ld, lane, wm0, wn0);         // L[r, c]
         if (r < a.diag_end) {
             T* Dt = Mk + (size_t)r * TS * ld + (size_t)r * TS;
             typename TL::acc_t dacc[2][2];
@@ -1484,9 +1499,9 @@ __device__ __forceinline__ void chain_step_body(const StepArgs& a, int b, unsign
                         for (int e = 0; e < 4; ++e)
                             blk[wm0 + i * 16 + Mfma<T>::row(lane, e)][wn0 + j * 16 + (lane & 15)] = (double)dacc[i][j][e];
                 __syncthreads();
-                leaf_body<T, true>(lds, k, (T*)a.M, (T*)a.W, a.mat, a.npad, c + 1, a.logdet, a.info);
+                leaf_body<T, true, WT>(lds, k, (T*)a.M, (T*)a.W, a.mat, a.npad, c + 1, a.logdet, a.info);
             } else {
-                TL::store(dacc, Dt, ld, lane, wm0, wn0);
+                TL::template store<WT>(dacc, Dt, ld, lane, wm0, wn0);
             }
         }
         return;
@@ -1522,7 +1537,7 @@ __device__ __forceinline__ void chain_step_body(const StepArgs& a, int b, unsign
                 TL::template mma_regs<true>(acc, pa[1], pb[1], (T*)lds, tid, lane, wm0, wn0);
             }
         }
-        TL::store(acc, Ct, ld, lane, wm0, wn0);
+        TL::template store<WT>(acc, Ct, ld, lane, wm0, wn0);
     }
 }
 
@@ -1560,7 +1575,7 @@ __global__ __launch_bounds__(256, 2) void wide_leaf_kernel(GemmArgs g, T* __rest
 // workgroups take the tasks in sequence order from one counter and a task waits only for what it reads or overwrites:
 //   * per (segment, component) a counter of finished tasks in the caller-owned workspace (zeroed by a memset node in
 //     front of the launch; the library still has no state);
-//   * a task of component k polls the counters of its segment's dependencies (<= 8, one lane each, relaxed agent-scope
+//   * a task of component k polls the counters of its segment's dependencies (<= 16, one lane each, relaxed agent-scope
 //     loads with s_sleep; BOUNDED: on expiry the failure word is set, every later wait returns at once, the launch
 //     drains and the components report info = -1), then ONE agent-scope acquire (buffer_inv sc1) and a workgroup
 //     barrier, then plain loads;
@@ -1579,11 +1594,16 @@ struct DagArgs {
     const DagSeg* segs; int nseg; int ntasks;
     int* ctl;
     unsigned spin_limit;
+    int flags;          // lcgp_sched.dag_flags
+#ifdef LCGP_DAG_TRACE
+    unsigned long long* trace;      // tool build only (make trace): per task [taken, ready, body done, published | segment | XCC]
+    int trace_cap;
+#endif
 };
 
 __device__ __forceinline__ int dag_load(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
-template <typename T>
+template <typename T, bool WT>
 __global__ __launch_bounds__(256, 2) void dag_kernel(DagArgs a) {
     constexpr int WIDE_LDS = 4 * KT * (128 + 16) * (int)sizeof(T);
     __shared__ __align__(16) unsigned char lds[WIDE_LDS > LEAF_LDS_BYTES ? WIDE_LDS : LEAF_LDS_BYTES];
@@ -1592,16 +1612,25 @@ __global__ __launch_bounds__(256, 2) void dag_kernel(DagArgs a) {
     const DagSeg* __restrict__ segs = a.segs;
     int* cnt = a.ctl + DAG_CTL;
     int seg = 0, memo_seg = -1, memo_k = -1;
+    if (tid == 0) sh_task = __hip_atomic_fetch_add(&a.ctl[0], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     for (;;) {
-        if (tid == 0) sh_task = __hip_atomic_fetch_add(&a.ctl[0], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // The task id was written to LDS by lane 0 at the END of the previous iteration.  The wait for that write is
+        // written out: hipcc (ROCm 7.2) emits this loop-header barrier as a bare s_barrier -- its waitcnt pass loses the
+        // pending ds_write across the back edge -- and the other waves then read the PREVIOUS task id now and then
+        // (two halves of a workgroup on different tasks; found on the GPU).
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __syncthreads();
         const int t = __builtin_amdgcn_readfirstlane(sh_task);
         if (t >= a.ntasks) break;
+#ifdef LCGP_DAG_TRACE
+        unsigned long long tr0 = 0, tr1 = 0, tr2 = 0;
+        if (tid == 0) tr0 = __builtin_amdgcn_s_memrealtime();
+#endif
         while (t >= segs[seg].t0 + segs[seg].ntasks) ++seg;
         const DagSeg& sg = segs[seg];
         const int b = t - sg.t0;
         const int k = b < sg.k_off ? b : (b - sg.k_off) % a.q;
-        if (seg != memo_seg || k != memo_k) {
+        if (seg != memo_seg || k != memo_k || (a.flags & 1)) {
             // (a workgroup that has already waited for this segment and component has seen everything they depend on)
             if (tid < sg.ndeps) {
                 const int* c = cnt + (size_t)sg.dep[tid] * a.q + k;
@@ -1616,9 +1645,21 @@ __global__ __launch_bounds__(256, 2) void dag_kernel(DagArgs a) {
                     }
                 }
             }
+            if ((a.flags & 32) && seg > 0 && tid < a.q) {
+                // diagnosis: every segment waits for ALL tasks of the segment before it (kernel boundaries in all but name)
+                const int* c = cnt + (size_t)(seg - 1) * a.q + tid;
+                const int need = segs[seg - 1].per_comp;
+                unsigned it = 0;
+                while (dag_load(c) < need) {
+                    __builtin_amdgcn_s_sleep(4);
+                    if (++it > a.spin_limit) { __hip_atomic_store(&a.ctl[1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+                }
+            }
+            if (a.flags & 32) __syncthreads();
             if (tid < 64) {      // the polling lanes are lanes of wave 0: its lane 0 fences after all of them have matched
                 if (tid == 0) {
-                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                    if (a.flags & 4) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+                    else __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 }
             }
@@ -1626,6 +1667,9 @@ __global__ __launch_bounds__(256, 2) void dag_kernel(DagArgs a) {
             memo_seg = seg;
             memo_k = k;
         }
+#ifdef LCGP_DAG_TRACE
+        if (tid == 0) tr1 = __builtin_amdgcn_s_memrealtime();
+#endif
         T* M = (T*)a.M;
         T* W = (T*)a.W;
         // (opaque copies: what the bodies derive from these would otherwise be computed once in front of the loop for all
@@ -1633,7 +1677,7 @@ __global__ __launch_bounds__(256, 2) void dag_kernel(DagArgs a) {
         const int npad = opaque_s(a.npad), nbk = opaque_s(a.nb), q = opaque_s(a.q);
         const size_t mat = (size_t)npad * npad;
         if (sg.kind == lcgp_fill::S_LEAF) {
-            leaf_body<T>(lds, k, M, W, mat, npad, sg.J, a.logdet, a.info);
+            leaf_body<T, false, WT>(lds, k, M, W, mat, npad, sg.J, a.logdet, a.info);
         } else if (sg.kind == lcgp_fill::S_STEP) {
             StepArgs sa;
             sa.M = a.M; sa.W = a.W; sa.mat = mat; sa.npad = npad; sa.nb = nbk;
@@ -1641,11 +1685,11 @@ __global__ __launch_bounds__(256, 2) void dag_kernel(DagArgs a) {
             sa.has_special = sg.has_special; sa.n_trmm = sg.n_trmm; sa.n_upd = sg.n_upd;
             sa.logdet = a.logdet; sa.info = a.info;
             sa.fs.njobs = 0; sa.fs.nblk = 0;
-            chain_step_body<T>(sa, b, lds);
+            chain_step_body<T, WT>(sa, b, lds);
             __builtin_amdgcn_s_setprio(0);
         } else if (sg.kind == lcgp_fill::S_TRAIL) {
             if (sg.with_leaf && b < q) {
-                leaf_body<T>(lds, b, M, W, mat, npad, sg.c_lo, a.logdet, a.info);
+                leaf_body<T, false, WT>(lds, b, M, W, mat, npad, sg.c_lo, a.logdet, a.info);
             } else {
                 GemmArgs g;
                 g.sA = g.sB = g.sC = mat; g.ldA = g.ldB = g.ldC = npad;
@@ -1654,12 +1698,12 @@ __global__ __launch_bounds__(256, 2) void dag_kernel(DagArgs a) {
                 const int lin = b - (sg.with_leaf ? q : 0);
                 if (sg.tiles128) {
                     g.nb = nbk / 2; g.p0 = sg.J / 2; g.p1 = sg.pe / 2; g.p2 = sg.c_lo / 2; g.p3 = sg.c_hi / 2;
-                    g.t0 = 0; g.skipq = sg.with_leaf;
-                    gemm_body<T, OP_SYRK, 128, 4>(g, lin, lds);
+                    g.t0 = sg.t_first; g.skipq = sg.with_leaf;
+                    gemm_body<T, OP_SYRK, 128, 4, WT>(g, lin, lds);
                 } else {
                     g.nb = nbk; g.p0 = sg.J; g.p1 = sg.pe; g.p2 = sg.c_lo; g.p3 = sg.c_hi;
-                    g.t0 = sg.with_leaf ? 1 : 0; g.skipq = 0;
-                    gemm_body<T, OP_SYRK, 64, 4>(g, lin, lds);
+                    g.t0 = sg.t_first + (sg.with_leaf ? 1 : 0); g.skipq = 0;
+                    gemm_body<T, OP_SYRK, 64, 4, WT>(g, lin, lds);
                 }
             }
         } else {
@@ -1667,14 +1711,36 @@ __global__ __launch_bounds__(256, 2) void dag_kernel(DagArgs a) {
             fs.M = a.M; fs.W = a.W; fs.V = a.V; fs.mat = mat; fs.npad = npad; fs.nb = nbk; fs.q = q;
             fs.njobs = 1; fs.nblk = sg.job.nblk;
             fs.job[0] = sg.job;
-            fill_dispatch<T>(fs, b, lds);
+            fill_dispatch<T, WT>(fs, b, lds);
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // every wave: its stores have left
+        // Every store of a body is write-through (gstore<true>): once every wave has drained its stores and the workgroup
+        // has met, the results are in memory and one lane publishes them.  The next task is requested BEFORE the drain, so
+        // that the round trip of that atomic overlaps it (the task is then held for the few microseconds of the drain
+        // only -- taking it earlier would park a chain task behind a long update tile).
+#ifdef LCGP_DAG_TRACE
+        if (tid == 0) tr2 = __builtin_amdgcn_s_memrealtime();
+#endif
+        int nxt = 0;
+        if (tid == 0 && !(a.flags & 16)) nxt = __hip_atomic_fetch_add(&a.ctl[0], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         __syncthreads();
         if (tid == 0) {
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (!WT || (a.flags & 2)) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
             __hip_atomic_fetch_add(cnt + (size_t)seg * a.q + k, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (a.flags & 16) nxt = __hip_atomic_fetch_add(&a.ctl[0], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            sh_task = nxt;
+#ifdef LCGP_DAG_TRACE
+            if (a.trace && t < a.trace_cap) {
+                unsigned long long* tr = a.trace + (size_t)t * 4;
+                unsigned xcc;
+                asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+                tr[0] = tr0; tr[1] = tr1; tr[2] = tr2;
+                tr[3] = __builtin_amdgcn_s_memrealtime() | ((unsigned long long)(xcc & 15) << 60) | ((unsigned long long)seg << 44);
+            }
+#endif
         }
     }
     if (dag_load(&a.ctl[1]) != 0)
@@ -2292,8 +2358,10 @@ inline lcgp_sched default_sched() {
                                    // (n = 2048: 1.12 -> 0.98 ms; at n = 4096 its tail is one ragged launch of long K loops
                                    // that loses to the one-launch W^T W: 2.54 vs 2.43 ms)
     s.dag = 0;                     // 1 = with a plan (lcgp_plan_build) the factorisation runs as ONE persistent launch with
-                                   // dependencies inside it (dag_kernel) instead of launch by launch
+                                   // dependencies inside it (dag_kernel) instead of launch by launch; 2 = the same with the
+                                   // trailing updates cut into near / far parts that alternate with the next panel's chain
     s.dag_spin_limit = 0;          // polls of one wait in that launch before it gives up (0 = 2,000,000, about two seconds)
+    s.dag_flags = 0;               // protocol variants of that launch (measurement / diagnosis; see the header)
     return s;
 }
 
@@ -2301,7 +2369,7 @@ inline int check_sched(const lcgp_sched& s) {
     if (s.outer_blocks < 0 || s.outer_blocks > 64) return bad("sched.outer_blocks must be in [0, 64]");
     if (s.syrk_small_tiles < 0 || s.trtri_small_tiles < 0 || s.lauum_small_tiles < 0 || s.trtri_level_small < 0 ||
         s.fill_leaf < 0 || s.fill_step < 0 || s.leaf_in_wide < 0 || s.progressive_tiles < 0 || s.progressive_lauum < 0 ||
-        s.dag < 0 || s.dag_spin_limit < 0)
+        s.dag < 0 || s.dag > 2 || s.dag_spin_limit < 0)
         return bad("sched fields must be >= 0");
     return 0;
 }
@@ -2319,7 +2387,8 @@ int launch_fill(hipStream_t st, const FillSet& fs) {
 
 // trailing update with the panel [J, pe) of the tile columns [c_lo, c_hi) (64-block units, all rows below)
 template <typename T>
-int potrf_trailing(hipStream_t st, const Ws& w, int J, int pe, int c_lo, int c_hi, bool tiles128, bool with_leaf) {
+int potrf_trailing(hipStream_t st, const Ws& w, int J, int pe, int c_lo, int c_hi, bool tiles128, bool with_leaf,
+                   int t_first = 0, int t_count = 0) {
     if (c_lo >= c_hi) return 0;
     T* M = (T*)(w.base + w.off_M);
     GemmArgs g;
@@ -2329,7 +2398,13 @@ int potrf_trailing(hipStream_t st, const Ws& w, int J, int pe, int c_lo, int c_h
     // plan decides); a launch with few tiles is bounded by the duration of one tile, which is 4x shorter on 64x64 tiles
     if (tiles128) {
         g.nb = w.nb / 2; g.p0 = J / 2; g.p1 = pe / 2; g.p2 = c_lo / 2; g.p3 = c_hi / 2;
-        const int nt = trapezoid_tiles(w.nb / 2, c_lo / 2, c_hi / 2);
+        const int nt = t_count > 0 ? t_count : trapezoid_tiles(w.nb / 2, c_lo / 2, c_hi / 2);
+        if (t_count > 0) {       // a sub-range of the update's tiles (the interleaved order of the persistent launch)
+            g.q = w.q; g.t0 = t_first; g.skipq = 0;
+            hipLaunchKernelGGL((tile_gemm<T, OP_SYRK, 128, 8>), dim3((unsigned)nt * w.q), dim3(512), 0, st, g);
+            CHECK_LAUNCH("tile_gemm");
+            return 0;
+        }
         if (with_leaf) {
             g.q = w.q; g.t0 = 0; g.skipq = 1;
             hipLaunchKernelGGL((wide_leaf_kernel<T, 128>), dim3((unsigned)(nt + 1) * w.q), dim3(256), 0, st, g, M,
@@ -2341,7 +2416,13 @@ int potrf_trailing(hipStream_t st, const Ws& w, int J, int pe, int c_lo, int c_h
         return launch_gemm<T, OP_SYRK, 128>(st, g, nt, w.q);
     }
     g.nb = w.nb; g.p0 = J; g.p1 = pe; g.p2 = c_lo; g.p3 = c_hi;
-    const int nt = trapezoid_tiles(w.nb, c_lo, c_hi);
+    const int nt = t_count > 0 ? t_count : trapezoid_tiles(w.nb, c_lo, c_hi);
+    if (t_count > 0) {
+        g.q = w.q; g.t0 = t_first; g.skipq = 0;
+        hipLaunchKernelGGL((tile_gemm<T, OP_SYRK, 64, 4>), dim3((unsigned)nt * w.q), dim3(256), 0, st, g);
+        CHECK_LAUNCH("tile_gemm");
+        return 0;
+    }
     if (with_leaf) {
         // tile 0 = the diagonal block itself: it belongs to the special workgroups (the chain steps of the panel have
         // already applied the panel to it)
@@ -2377,8 +2458,9 @@ inline lcgp_fill::PlanParams plan_params(int dtype, int nb, int q, bool with_inv
     pp.ob = sc.outer_blocks < 1 ? (dtype == LCGP_F32 ? 8 : 4) : sc.outer_blocks;
     pp.syrk_small_tiles = sc.syrk_small_tiles; pp.fill_leaf = sc.fill_leaf; pp.fill_step = sc.fill_step;
     pp.leaf_in_wide = sc.leaf_in_wide;
+    pp.interleaved = sc.dag == 2;
     bool prog = false;
-    if (with_inverse && sc.progressive_tiles > 0 && pp.ob >= 2 && (pp.ob & (pp.ob - 1)) == 0) {
+    if (!pp.interleaved && with_inverse && sc.progressive_tiles > 0 && pp.ob >= 2 && (pp.ob & (pp.ob - 1)) == 0) {
         const int nb2 = nb / 2;
         prog = (long long)q * (nb2 * (nb2 + 1) / 2) <= sc.progressive_tiles;
     }
@@ -2475,9 +2557,15 @@ int do_potrf(hipStream_t st, const Ws& w, const lcgp_sched& sc, bool stats_zeroe
             a.nseg = h->nseg; a.ntasks = h->ntasks;
             a.ctl = ctl;
             a.spin_limit = h->sched.dag_spin_limit > 0 ? (unsigned)h->sched.dag_spin_limit : 2000000u;
+            a.flags = h->sched.dag_flags;
+#ifdef LCGP_DAG_TRACE
+            a.trace = (unsigned long long*)(w.base + w.off_trace);
+            a.trace_cap = DAG_TRACE_CAP;
+#endif
             long grid = 2L * h->num_cu;
             if (grid > h->ntasks) grid = h->ntasks;
-            hipLaunchKernelGGL((dag_kernel<T>), dim3((unsigned)grid), dim3(256), 0, st, a);
+            if (a.flags & 8) hipLaunchKernelGGL((dag_kernel<T, false>), dim3((unsigned)grid), dim3(256), 0, st, a);
+            else hipLaunchKernelGGL((dag_kernel<T, true>), dim3((unsigned)grid), dim3(256), 0, st, a);
             CHECK_LAUNCH("dag_kernel");
             return 0;
         }
@@ -2519,7 +2607,7 @@ int do_potrf(hipStream_t st, const Ws& w, const lcgp_sched& sc, bool stats_zeroe
                 break;
             }
             case lcgp_fill::L_TRAIL:
-                rc = potrf_trailing<T>(st, w, l.J, l.pe, l.c_lo, l.c_hi, l.tiles128 != 0, l.with_leaf != 0);
+                rc = potrf_trailing<T>(st, w, l.J, l.pe, l.c_lo, l.c_hi, l.tiles128 != 0, l.with_leaf != 0, l.t_first, l.t_count);
                 break;
             default:
                 rc = launch_fill<T>(st, fs);

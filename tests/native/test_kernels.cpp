@@ -283,10 +283,13 @@ static void run_case(int n, int d, int p, int q, bool rep, unsigned seed) {
 
     // the same call with a caller-owned plan: launch by launch (identical bits) and as the one persistent launch with
     // dependencies inside it (sched.dag = 1: same bodies, same arithmetic per tile, so the same bits as well)
-    for (int dagmode = 0; dagmode < 2; ++dagmode) {
+    const char* fl = getenv("LCGP_TEST_DAG_FLAGS");
+    const int reps = getenv("LCGP_TEST_DAG_REPS") ? atoi(getenv("LCGP_TEST_DAG_REPS")) : 3;
+    for (int dagmode = 0; dagmode < 3; ++dagmode) {
         lcgp_sched sc;
         LCHK(lcgp_sched_default(&sc));
         sc.dag = dagmode;
+        sc.dag_flags = fl ? atoi(fl) : 0;
         size_t pb = 0;
         LCHK(lcgp_plan_bytes(dtype, n, q, 1, &sc, &pb));
         std::vector<char> plan(pb);
@@ -296,18 +299,36 @@ static void run_case(int n, int d, int p, int q, bool rep, unsigned seed) {
         void* dplan;
         HIPCHK(hipMalloc(&dplan, pb));
         HIPCHK(hipMemcpy(dplan, plan.data(), pb, hipMemcpyHostToDevice));
-        HIPCHK(hipMemset(ws, 0xff, wsb));
-        HIPCHK(hipMemset(dout, 0, (size_t)q * ow * 8));
-        LCHK(lcgp_nll_grad(nullptr, dtype, n, d, p, q, dx, dY, srp, dtheta, ws, dout, nullptr, plan.data(), dplan));
-        HIPCHK(hipDeviceSynchronize());
-        vec hout2((size_t)q * ow);
-        HIPCHK(hipMemcpy(hout2.data(), dout, hout2.size() * 8, hipMemcpyDeviceToHost));
         double e = 0;
-        for (size_t i = 0; i < hout2.size(); ++i) e = fmax(e, fabs(hout2[i] - hout[i]) / (1e-300 + fabs(hout[i])));
-        char what[96];
-        snprintf(what, sizeof(what), "%s (%d launches, %d segments, %d tasks) vs per-call plan",
-                 dagmode ? "persistent launch" : "caller-owned plan", nl, ns, nt);
-        report(what, e, 0.0);
+        int nbad = 0;
+        for (int r = 0; r < (dagmode ? reps : 1); ++r) {
+            HIPCHK(hipMemset(ws, r & 1 ? 0x00 : 0xff, wsb));
+            HIPCHK(hipMemset(dout, 0, (size_t)q * ow * 8));
+            LCHK(lcgp_nll_grad(nullptr, dtype, n, d, p, q, dx, dY, srp, dtheta, ws, dout, nullptr, plan.data(), dplan));
+            HIPCHK(hipDeviceSynchronize());
+            vec hout2((size_t)q * ow);
+            HIPCHK(hipMemcpy(hout2.data(), dout, hout2.size() * 8, hipMemcpyDeviceToHost));
+            double er = 0;
+            for (size_t i = 0; i < hout2.size(); ++i) {
+                const double df = fabs(hout2[i] - hout[i]) / (1e-300 + fabs(hout[i]));
+                er = fmax(er, std::isfinite(df) ? df : 1e300);
+            }
+            if (er > (dagmode == 2 ? 1e-11 : 0.0)) {
+                ++nbad;
+                if (getenv("LCGP_TEST_DAG_VERBOSE")) {
+                    printf("    run %d mode %d: differing entries (row: col got want):", r, dagmode);
+                    int shown = 0;
+                    for (size_t i = 0; i < hout2.size() && shown < 12; ++i)
+                        if (hout2[i] != hout[i]) { printf(" [%zu:%zu %.6g %.6g]", i / ow, i % ow, hout2[i], hout[i]); ++shown; }
+                    printf("\n");
+                }
+            }
+            e = fmax(e, er);
+        }
+        char what[112];
+        snprintf(what, sizeof(what), "%s (%d launches, %d segments, %d tasks; %d bad runs) vs per-call plan",
+                 dagmode == 2 ? "persistent, interleaved" : dagmode ? "persistent launch" : "caller-owned plan", nl, ns, nt, nbad);
+        report(what, e, dagmode == 2 ? (sizeof(T) == 8 ? 1e-11 : 1e-3) : 0.0);
         HIPCHK(hipFree(dplan));
     }
 

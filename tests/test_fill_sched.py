@@ -24,9 +24,9 @@ def dump_plan(tmp_path_factory):
                     os.path.join(ROOT, 'tests', 'native', 'dump_plan.cpp')], check=True)
 
     def run(nb, q, ob, syrk_small=2000, fill_leaf=248, fill_step=248, leaf_in_wide=1024, progressive=1, far_rides=1, with_dupd=1,
-            dag=0):
+            dag=0, interleaved=0):
         out = subprocess.run([exe] + [str(v) for v in (nb, q, ob, syrk_small, fill_leaf, fill_step, leaf_in_wide, progressive,
-                                                       far_rides, with_dupd, dag)],
+                                                       far_rides, with_dupd, dag, interleaved)],
                              check=True, capture_output=True, text=True).stdout
         assert 'FAILED' not in out
         launches = []
@@ -34,11 +34,11 @@ def dump_plan(tmp_path_factory):
         for line in out.splitlines():
             f = line.split()
             if f[0] == 'S':
-                v = [int(x) for x in f[1:27]]
+                v = [int(x) for x in f[1:29]]
                 keys = ('kind t0 ntasks per_comp k_off J pe c diag_end has_special n_trmm n_upd c_lo c_hi tiles128 with_leaf '
-                        'type nblk jt0 R0 R1 j0 j1 kb0 kb1 ndeps').split()
+                        'type nblk jt0 R0 R1 j0 j1 kb0 kb1 t_first t_count ndeps').split()
                 sg = dict(zip(keys, v))
-                sg['deps'] = [tuple(int(y) for y in x.split(':')) for x in f[27:]]
+                sg['deps'] = [tuple(int(y) for y in x.split(':')) for x in f[29:]]
                 assert len(sg['deps']) == sg['ndeps']
                 sg['jobs'] = [dict(type=sg['type'], nblk=sg['nblk'], t0=sg['jt0'], R0=sg['R0'], R1=sg['R1'], j0=sg['j0'],
                                    j1=sg['j1'], kb0=sg['kb0'], kb1=sg['kb1'])] if sg['kind'] == 4 else []
@@ -47,7 +47,8 @@ def dump_plan(tmp_path_factory):
             v = [int(x) for x in f[1:]]
             if f[0] == 'L':
                 launches.append(dict(kind=v[0], J=v[1], pe=v[2], c=v[3], diag_end=v[4], has_special=v[5], n_trmm=v[6],
-                                     n_upd=v[7], c_lo=v[8], c_hi=v[9], tiles128=v[10], with_leaf=v[11], nblk=v[13], jobs=[]))
+                                     n_upd=v[7], c_lo=v[8], c_hi=v[9], tiles128=v[10], with_leaf=v[11], nblk=v[13],
+                                     t_first=v[14], t_count=v[15], jobs=[]))
             else:
                 launches[-1]['jobs'].append(dict(type=v[0], nblk=v[1], t0=v[2], R0=v[3], R1=v[4], j0=v[5], j1=v[6],
                                                  kb0=v[7], kb1=v[8]))
@@ -143,6 +144,22 @@ class Replay:
 
     def run_trail(self, l):
         J, pe = l['J'], l['pe']
+        if l.get('t_count', 0):
+            # a sub-range [t_first, t_first + t_count) of the tiles, column-major from tile column c_lo on (gemm_body, OP_SYRK);
+            # on 128x128 tiles a tile is 2 x 2 blocks (the diagonal ones hold 3)
+            u = 2 if l['tiles128'] else 1
+            nbt = self.nb // u
+            tiles = []
+            for C in range(l['c_lo'] // u, nbt):
+                for r in range(C, nbt):
+                    tiles.append((r, C))
+            for r, C in tiles[l['t_first']:l['t_first'] + l['t_count']]:
+                self.new_item()
+                for cc in range(C * u, (C + 1) * u):
+                    for rr in range(max(r * u, cc), (r + 1) * u):
+                        t = self.rd('M', rr, rr + 1, cc, cc + 1) - self.rd('M', rr, rr + 1, J, pe) @ self.rd('M', cc, cc + 1, J, pe).T
+                        self.wr('M', rr, cc, t)
+            return
         for C in range(l['c_lo'], l['c_hi']):
             for r in range(C, self.nb):
                 self.new_item()
@@ -371,7 +388,7 @@ def test_task_graph_dependencies_cover_every_block_hazard(dump_plan, nb, q, ob, 
     launches, segs = dump_plan(nb, q, ob, progressive=progressive, dag=1, **kw)
     r = DagReplay(nb, q, seed=5 * nb + q)
     maxdep = r.run_dag(segs)
-    assert maxdep <= 8
+    assert maxdep <= 16
     r.check(inverse=bool(progressive))
     # the graph holds exactly the work of the launch list
     assert sum(sg['ntasks'] for sg in segs if sg['kind'] == 4) == sum(jb['nblk'] for l in launches for jb in l['jobs'])
@@ -393,3 +410,25 @@ def test_task_graph_mutations_are_caught(dump_plan):
             except AssertionError:
                 caught += 1
     assert total > 20 and caught == total, (caught, total)
+
+
+@pytest.mark.parametrize('nb,q,ob,kw', [(64, 8, 4, {}), (64, 1, 4, {}), (64, 2, 4, {}), (16, 4, 4, {}), (32, 6, 4, {}), (18, 1, 4, {}),
+                                        (10, 3, 4, {}), (6, 1, 4, {}), (4, 1, 4, {}), (2, 1, 4, {}), (24, 2, 8, {}), (20, 1, 8, {}),
+                                        (12, 1, 2, {}), (14, 2, 6, {}), (16, 1, 3, {}), (32, 1, 4, dict(syrk_small=0)),
+                                        (32, 3, 2, dict(syrk_small=0)), (64, 4, 4, dict(syrk_small=100))])
+def test_interleaved_order_for_the_persistent_launch(dump_plan, nb, q, ob, kw):
+    """near / far trailing updates, the far part in chunks that alternate with the next panel's chain (Planner::
+    run_interleaved): valid as a launch list, and as a task graph with the derived dependencies"""
+    launches, segs = dump_plan(nb, q, ob, progressive=0, dag=1, interleaved=1, **kw)
+    r = Replay(nb, q, seed=7 * nb + q)
+    r.run(launches)
+    r.check(inverse=False)
+    r = DagReplay(nb, q, seed=7 * nb + q)
+    assert r.run_dag(segs) <= 16
+    r.check(inverse=False)
+    # a chain launch never waits for a far chunk of the update before it: that is the point of the order
+    kinds = {i: sg for i, sg in enumerate(segs)}
+    for i, sg in enumerate(segs):
+        if sg['kind'] in (1, 2):
+            for d, _ in sg['deps']:
+                assert not (kinds[d]['kind'] == 3 and kinds[d]['t_count'] > 0 and kinds[d]['c_lo'] > sg['pe']), (i, sg, kinds[d])

@@ -31,7 +31,7 @@ CASES = [
                           dict(syrk_small_tiles=16, fill_leaf=40, fill_step=56), dict(syrk_small_tiles=1, fill_leaf=8, fill_step=8),
                           dict(progressive_tiles=1 << 30, syrk_small_tiles=16)]),
     (405, 2048, 3, 12, 6, [{}, dict(progressive_tiles=1 << 30, fill_leaf=30, fill_step=18)]),
-    (406, 1000, 3, 4, 8, [{}]),
+    (406, 1000, 3, 9, 8, [{}]),
     (407, 1100, 2, 3, 1, [{}, dict(progressive_lauum=0)]),
 ]
 
@@ -55,6 +55,22 @@ def test_persistent_launch_equals_launch_by_launch(seed, n, d, p, q, variants):
                 out = eng.out_dev.cpu().numpy()
                 assert np.array_equal(out, ref_out), (fields, rep, float(np.max(np.abs(out - ref_out))))
                 assert v == ref_v and np.array_equal(g, ref_g), fields
+            # the persistent launch with its own task order (near / far updates alternating with the chain): other tile
+            # shapes in places, so equal to rounding, and bitwise repeatable
+            eng.sched = _sched(dag=2, **fields)
+            assert eng.plan_info()['segments'] > 0
+            v2, g2 = m.loss_and_grad(u)
+            out2 = eng.out_dev.cpu().numpy().copy()
+            assert abs(v2 - ref_v) <= 1e-11 * abs(ref_v), fields
+            assert np.max(np.abs(g2 - ref_g)) <= 1e-10 * np.max(np.abs(ref_g)), fields
+            m.loss_and_grad(u)
+            assert np.array_equal(eng.out_dev.cpu().numpy(), out2), fields
+            # ... and the same list executed launch by launch (no device copy of the plan)
+            eng.use_plan = False
+            eng.sched = _sched(dag=2, **fields)
+            v3, g3 = m.loss_and_grad(u)
+            eng.use_plan = True
+            assert abs(v3 - ref_v) <= 1e-11 * abs(ref_v) and np.max(np.abs(g3 - ref_g)) <= 1e-10 * np.max(np.abs(ref_g)), fields
     finally:
         eng.sched = None
 

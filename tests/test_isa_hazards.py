@@ -38,3 +38,43 @@ def test_checker_flags_a_dpp_read_right_after_a_valu_write():
 @pytest.mark.skipif(shutil.which('hipcc') is None, reason='needs hipcc')
 def test_product_kernels_have_no_dpp_hazard():
     assert chk.main() == 0
+
+
+# ---- barriers of the persistent kernel: the LDS write of the task id must be complete before the loop-header barrier ----
+spec2 = importlib.util.spec_from_file_location('check_barrier_waits', os.path.join(ROOT, 'tools', 'check_barrier_waits.py'))
+cbw = importlib.util.module_from_spec(spec2)
+spec2.loader.exec_module(cbw)
+
+
+def test_barrier_checker_flags_the_pattern_hipcc_emitted():
+    """what ROCm 7.2 made of dag_kernel's loop before the wait was written out: the task id is stored to LDS at the end of
+    an iteration and the loop header is a bare s_barrier followed by the other waves' ds_read"""
+    bad = """
+.LBB18_6:
+	ds_write_b32 v228, v2
+.LBB18_7:
+	s_or_b64 exec, exec, s[0:1]
+	s_mov_b64 s[0:1], 0
+.LBB18_8:
+	s_and_b64 vcc, exec, s[0:1]
+	s_cbranch_vccnz .LBB18_958
+.LBB18_9:
+	s_barrier
+	ds_read_b32 v2, v228
+	s_waitcnt lgkmcnt(0)
+.LBB18_958:
+	s_endpgm
+""".splitlines()
+    n, problems = cbw.check(bad)
+    assert n == 1 and problems
+    good = [ln for ln in bad]
+    good.insert(good.index('\ts_barrier'), '\ts_waitcnt lgkmcnt(0)')
+    assert not cbw.check(good)[1]
+    same_block = ['\tds_write_b32 v1, v2', '\ts_barrier']
+    assert cbw.check(same_block)[1]
+    assert not cbw.check(['\tds_write_b32 v1, v2', '\ts_waitcnt vmcnt(0) lgkmcnt(0)', '\ts_barrier'])[1]
+
+
+@pytest.mark.skipif(shutil.which('hipcc') is None, reason='needs hipcc')
+def test_persistent_kernel_barriers_wait_for_lds_writes():
+    assert cbw.main() == 0
