@@ -273,25 +273,48 @@ struct PlanParams {
                              // then forms A^-1 in one launch after the factorisation)
     bool interleaved = false; // order for the persistent launch (Planner::run_interleaved): near / far trailing updates,
                               // the far part cut into chunks that alternate with the next panel's chain
+    bool with_trtri = false;  // interleaved: the triangular inverse W = L^-1 (level-parallel products) is part of the same
+                              // sequence -- its early levels fill the chain-bound end of the factorisation
+    int trtri_all_small = 0;  // ... every level on 64 x 64 tiles (small problems); else only the first
+    int tri_fill_from = 256;  // ... they start to ride when a chain step's share of the far update drops below this many blocks
+    bool psolve = true;       // ... and the rows below the chain rows are solved per panel with the panel's 256 x 256 inverse
 };
 
 enum LaunchKind {
     L_LEAF = 1,              // diagonal block J (+ filler)
     L_STEP = 2,              // chain step of block column c (+ filler)
     L_TRAIL = 3,             // wide trailing update of panel [J, pe) on the block columns [c_lo, c_hi)
-    L_FILL = 4               // filler jobs on their own
+    L_FILL = 4,              // filler jobs on their own
+    L_TRI = 5,               // one step (T = L21 W11 or W21 = -W22 T) of one level of the triangular inverse, a range of pairs
+    L_PSOLVE = 6             // panel solve of the rows below the chain rows: L[R, jt] = sum_{kt <= jt} A[R, kt] W_PP[jt, kt]^T for the
+                             // 128-column tile jt (= c_lo) of the panel [J, pe) and the 128-row tiles from block row r_lo on
 };
 
 struct Launch {
     int kind = 0;
     int J = 0, pe = 0, c = 0;
     int diag_end = 0, has_special = 0, n_trmm = 0, n_upd = 0;       // L_STEP
+    int trmm_r0 = 0, upd_r0 = 0;                                    // L_STEP: first block row of its n_trmm solve tiles / n_upd delayed
+                                                                    // update tiles (0 = c + 1 / c + 2: all rows below the diagonal)
     int c_lo = 0, c_hi = 0, tiles128 = 0, with_leaf = 0;            // L_TRAIL
     int t_first = 0, t_count = 0;                                   // L_TRAIL: a sub-range of its tiles (t_count = 0: all of them)
+    int r_lo = 0, r_hi = 0;                                         // L_TRAIL: block rows [max(column, r_lo), r_hi) of every block
+                                                                    // column (r_hi = 0: down to the last row)
+    int tri_mb = 0, tri_p0 = 0, tri_np = 0, tri_w = 0;              // L_TRI: level block size (tiles), first pair, pairs, 0 = T / 1 = W
+                                                                    // (tiles128 = tile size)
     FillSet fs;                                                     // job descriptors (base pointers are set by the executor)
 };
 
 inline long rect_tiles(int nb, int c_lo, int c_hi) { return syrk_tiles(nb / 2, c_lo, c_hi); }
+// tiles of a trailing-update region: tile columns [c_lo, c_hi), in column c the tile rows [max(c, r_lo), r_hi)
+inline long region_tiles(int c_lo, int c_hi, int r_lo, int r_hi) {
+    long n = 0;
+    for (int c = c_lo; c < c_hi; ++c) {
+        const int a = c > r_lo ? c : r_lo;
+        if (r_hi > a) n += r_hi - a;
+    }
+    return n;
+}
 inline int trapezoid_tiles(int nb, int c_lo, int c_hi) { return (c_hi - c_lo) * nb - (c_lo + c_hi - 1) * (c_hi - c_lo) / 2; }
 
 class Planner {
@@ -311,59 +334,168 @@ class Planner {
     void run_interleaved() {
         const int nb = pp.nb, ob = pp.ob, q = pp.q;
         const bool t128 = (ob & 1) == 0;
-        struct Far { int J, pe, c_lo, tiles128; long ntiles; } far = {0, 0, 0, 0, 0};
-        for (int J = 0; J < nb; J += ob) {
+        // pending "fill" work of the previous panel: the rest of its near columns and its far columns (in chunks)
+        struct Fill { bool on; Launch l; long ntiles; long given; };
+        Fill rest = {false, Launch(), 0, 0}, far = {false, Launch(), 0, 0};
+        auto emit_chunk = [&](Fill& f, long upto) {
+            if (!f.on || upto > f.ntiles) upto = f.on ? f.ntiles : 0;
+            if (!f.on || upto <= f.given) return;
+            Launch l = f.l;
+            l.t_first = (int)f.given;
+            l.t_count = (int)(upto - f.given);
+            launches.push_back(l);
+            f.given = upto;
+        };
+        std::vector<Launch> bulk;        // bulk parts of this panel's chain steps, waiting for a slot in the order
+        // Units of the triangular inverse (one step of one level for a run of pairs), sorted by the panel that completes
+        // their rows of L, then by level: every unit comes behind the units it reads from.
+        struct Tri { Launch l; int ready; long blocks; };
+        std::vector<Tri> tri;
+        if (pp.with_trtri) {
+            for (int P = 0; P * ob < nb; ++P) {
+                for (int mb64 = 1; mb64 < nb; mb64 *= 2) {
+                    const int tm128 = (mb64 == 1 || pp.trtri_all_small || !t128) ? 0 : 1;
+                    const int u = tm128 ? 2 : 1, mb = mb64 / u, nbt = nb / u;
+                    for (int w = 0; w < 2; ++w) {
+                        int first = -1, count = 0;
+                        auto flush = [&]() {
+                            if (count == 0) return;
+                            Tri t;
+                            t.l = Launch();
+                            t.l.kind = L_TRI; t.l.tiles128 = tm128; t.l.tri_mb = mb; t.l.tri_p0 = first; t.l.tri_np = count; t.l.tri_w = w;
+                            t.l.fs.njobs = 0; t.l.fs.nblk = 0;
+                            t.ready = P;
+                            t.blocks = (long)count * mb * mb * q;
+                            tri.push_back(t);
+                            count = 0; first = -1;
+                        };
+                        for (int pr = 0; (2 * pr + 1) * mb < nbt; ++pr) {
+                            int last = (2 * pr + 2) * mb * u;            // one past the last 64-block row the pair reads
+                            if (last > nb) last = nb;
+                            const int rp = (last - 1) / ob;
+                            if (rp == P) { if (count == 0) first = pr; ++count; }
+                            else flush();
+                        }
+                        flush();
+                    }
+                }
+            }
+        }
+        // Rows below the chain rows: with 128-aligned panels and the inverse in the sequence they skip the 64-column steps
+        // altogether -- once the panel's diagonal block and ITS inverse W_PP exist (the first levels of the triangular
+        // inverse, which ride right behind the panel's chain), L[R, panel] = A[R, panel] W_PP^T is ONE product on 128 x 128
+        // tiles per 128 columns (a quarter of the arithmetic of the four solve + update steps, at the tile kernel's rate).
+        const bool use_psolve = pp.with_trtri && t128 && !pp.trtri_all_small && pp.psolve;
+        size_t tri_next = 0;
+        int panel_idx = 0;
+        auto emit_tri = [&](long budget_blocks, int done_panel) {
+            // units whose rows of L are complete (panels <= done_panel), in order, up to the budget
+            while (tri_next < tri.size() && tri[tri_next].ready <= done_panel && budget_blocks > 0) {
+                launches.push_back(tri[tri_next].l);
+                budget_blocks -= tri[tri_next].blocks;
+                ++tri_next;
+            }
+        };
+        for (int J = 0; J < nb; J += ob, ++panel_idx) {
             const int pe = J + ob < nb ? J + ob : nb;
-            // the chain of this panel, alternating with the chunks of the previous panel's far update
-            std::vector<Launch> chain;
+            const int ne = pe + ob < nb ? pe + ob : nb;            // end of the next panel
+            const int rch = ne + ob < nb ? ne + ob : nb;           // chain rows: this panel's, the next one's and the one after
             {
                 Launch l;
                 l.kind = L_LEAF; l.J = J; l.pe = pe;
                 l.fs.njobs = 0; l.fs.nblk = 0;
-                chain.push_back(l);
+                launches.push_back(l);
             }
-            for (int c = J; c < pe && c + 1 < nb; ++c) {
+            emit_chunk(rest, rest.ntiles);                          // (needed by the bulk rows of this panel's chain)
+            int nsteps = 0;
+            for (int c = J; c < pe && c + 1 < nb; ++c) ++nsteps;
+            int si = 0;
+            for (int c = J; c < pe && c + 1 < nb; ++c, ++si) {
+                // chain part: the rows the following diagonal blocks need; bulk part: all rows below them
+                const bool upd = c > J && c + 1 < pe;
                 Launch l;
                 l.kind = L_STEP; l.J = J; l.pe = pe; l.c = c;
                 l.diag_end = pe;
-                l.has_special = c + 1 < pe ? 1 : 0;
-                l.n_trmm = nb - 1 - c;
-                l.n_upd = (c > J && c + 1 < pe) ? nb - (c + 1) - 1 : 0;
                 l.fs.njobs = 0; l.fs.nblk = 0;
-                chain.push_back(l);
-            }
-            const int nch = (int)chain.size();
-            long given = 0;
-            for (int i = 0; i < nch; ++i) {
-                launches.push_back(chain[i]);
-                if (far.ntiles > 0) {
-                    const long upto = far.ntiles * (i + 1) / nch;
-                    if (upto > given) {
-                        Launch l;
-                        l.kind = L_TRAIL; l.J = far.J; l.pe = far.pe; l.c_lo = far.c_lo; l.c_hi = nb; l.tiles128 = far.tiles128;
-                        l.with_leaf = 0; l.t_first = (int)given; l.t_count = (int)(upto - given);
-                        l.fs.njobs = 0; l.fs.nblk = 0;
-                        launches.push_back(l);
-                        given = upto;
-                    }
+                Launch ch = l, bk = l;
+                ch.has_special = c + 1 < pe ? 1 : 0;
+                ch.trmm_r0 = c + 1; ch.n_trmm = (rch < nb ? rch : nb) - (c + 1);
+                ch.upd_r0 = c + 2; ch.n_upd = upd ? (rch < nb ? rch : nb) - (c + 2) : 0;
+                if (ch.n_upd < 0) ch.n_upd = 0;
+                bk.has_special = 0;
+                bk.trmm_r0 = rch; bk.n_trmm = use_psolve ? 0 : nb - rch;
+                bk.upd_r0 = rch; bk.n_upd = (upd && !use_psolve) ? nb - rch : 0;
+                launches.push_back(ch);
+                // fill behind the chain step: the bulk rows of the step before, a share of the far update
+                if (!bulk.empty()) { launches.push_back(bulk.back()); bulk.pop_back(); }
+                const long far_before = far.on ? far.given : 0;
+                emit_chunk(far, far.ntiles * (si + 1) / (nsteps > 0 ? nsteps : 1));
+                // the chain-bound end of the factorisation: units of the inverse whose rows of L were complete TWO panels ago
+                // (their last producers are well behind in the sequence) take the room the far update no longer fills
+                {
+                    const long far_blocks = ((far.on ? far.given : 0) - far_before) * (far.on && far.l.tiles128 ? 4 : 1) * q;
+                    if (far_blocks < pp.tri_fill_from) emit_tri(pp.tri_fill_from - far_blocks, panel_idx - 2);
                 }
+                if (bk.n_trmm > 0) bulk.push_back(bk);
             }
-            far.ntiles = 0;
-            if (pe >= nb) break;
-            // near part: the columns of the next panel; far part: everything to the right of them
-            const int ne = pe + ob < nb ? pe + ob : nb;
-            const bool w128 = t128 && (long long)q * trapezoid_tiles(nb / 2, pe / 2, nb / 2) >= pp.syrk_small_tiles;
-            {
+            emit_chunk(far, far.ntiles);
+            far.on = false; rest.on = false;
+            if (pe < nb) {
+                // the near update in two parts: what the next chain reads (on 64 x 64 tiles: it is on the critical path) ...
                 Launch l;
-                l.kind = L_TRAIL; l.J = J; l.pe = pe; l.c_lo = pe; l.c_hi = ne; l.tiles128 = w128 ? 1 : 0; l.with_leaf = 0;
+                l.kind = L_TRAIL; l.J = J; l.pe = pe; l.c_lo = pe; l.c_hi = ne; l.tiles128 = 0; l.with_leaf = 0;
+                l.r_lo = 0; l.r_hi = rch;
+                l.t_first = 0; l.t_count = (int)region_tiles(pe, ne, 0, rch);
                 l.fs.njobs = 0; l.fs.nblk = 0;
                 launches.push_back(l);
             }
+            while (!bulk.empty()) { launches.push_back(bulk.back()); bulk.pop_back(); }
+            if (use_psolve) {
+                // the panel's own levels of the inverse (the 64-block pairs inside it, then its 128-blocks), then the solve
+                // of the rows below, column tile by column tile from the right (a tile reads the ones to its left)
+                size_t keep = 0;
+                std::vector<Tri> later;
+                for (size_t i = tri_next; i < tri.size(); ++i) {
+                    const Launch& tl = tri[i].l;
+                    const int span = tl.tri_mb * (tl.tiles128 ? 2 : 1) * 2;        // 64-blocks a pair covers
+                    if (tri[i].ready == panel_idx && span <= ob) launches.push_back(tl);
+                    else later.push_back(tri[i]);
+                    (void)keep;
+                }
+                tri.erase(tri.begin() + tri_next, tri.end());
+                tri.insert(tri.end(), later.begin(), later.end());
+                if (rch < nb)
+                    for (int jt = (pe - J) / 2 - 1; jt >= 0; --jt) {
+                        Launch l;
+                        l.kind = L_PSOLVE; l.J = J; l.pe = pe; l.c_lo = jt; l.r_lo = rch; l.tiles128 = 1;
+                        l.fs.njobs = 0; l.fs.nblk = 0;
+                        launches.push_back(l);
+                    }
+            }
+            if (pe >= nb) break;
+            // ... and its rows below (needed by the bulk rows of the next chain), then the far columns
+            if (rch < nb) {
+                rest.on = true; rest.given = 0;
+                Launch& l = rest.l;
+                l = Launch();
+                l.kind = L_TRAIL; l.J = J; l.pe = pe; l.c_lo = pe; l.c_hi = ne; l.with_leaf = 0;
+                l.tiles128 = t128 ? 1 : 0;
+                l.r_lo = rch; l.r_hi = nb;
+                l.fs.njobs = 0; l.fs.nblk = 0;
+                rest.ntiles = t128 ? region_tiles(pe / 2, ne / 2, rch / 2, nb / 2) : region_tiles(pe, ne, rch, nb);
+            }
             if (ne < nb) {
-                far.J = J; far.pe = pe; far.c_lo = ne; far.tiles128 = w128 ? 1 : 0;
-                far.ntiles = w128 ? trapezoid_tiles(nb / 2, ne / 2, nb / 2) : trapezoid_tiles(nb, ne, nb);
+                far.on = true; far.given = 0;
+                Launch& l = far.l;
+                l = Launch();
+                l.kind = L_TRAIL; l.J = J; l.pe = pe; l.c_lo = ne; l.c_hi = nb; l.with_leaf = 0;
+                l.tiles128 = t128 ? 1 : 0;
+                l.r_lo = 0; l.r_hi = nb;
+                l.fs.njobs = 0; l.fs.nblk = 0;
+                far.ntiles = t128 ? region_tiles(ne / 2, nb / 2, 0, nb / 2) : region_tiles(ne, nb, 0, nb);
             }
         }
+        emit_tri(1L << 60, 1 << 30);          // the rest of the inverse behind the factorisation
     }
 
     void run() {
@@ -584,7 +716,7 @@ class Planner {
 // ---------------------------------------------------------------------------------------------------
 constexpr int DAG_MAXDEP = 16;
 
-enum SegKind { S_LEAF = 1, S_STEP = 2, S_TRAIL = 3, S_FILL = 4 };
+enum SegKind { S_LEAF = 1, S_STEP = 2, S_TRAIL = 3, S_FILL = 4, S_TRI = 5, S_PSOLVE = 6 };
 
 struct DagSeg {
     int kind;
@@ -597,6 +729,9 @@ struct DagSeg {
     int J, pe, c, diag_end, has_special, n_trmm, n_upd;      // S_LEAF (J) / S_STEP
     int c_lo, c_hi, tiles128, with_leaf;                     // S_TRAIL (+ J, pe)
     int t_first, t_count;                                    // S_TRAIL: a sub-range of the update's tiles (t_count = 0: all)
+    int r_lo, r_hi;                                          // S_TRAIL: block rows [max(column, r_lo), r_hi) (r_hi = 0: all)
+    int trmm_r0, upd_r0;                                     // S_STEP: first block row of the solve / delayed-update tiles
+    int tri_mb, tri_p0, tri_np, tri_w;                       // S_TRI (+ tiles128)
     FillJob job;                                             // S_FILL
 };
 
@@ -629,6 +764,8 @@ class DagBuilder {
                 DagSeg s = blank(S_STEP);
                 s.J = l.J; s.pe = l.pe; s.c = l.c; s.diag_end = l.diag_end; s.has_special = l.has_special;
                 s.n_trmm = l.n_trmm; s.n_upd = l.n_upd;
+                s.trmm_r0 = l.trmm_r0 ? l.trmm_r0 : l.c + 1;
+                s.upd_r0 = l.upd_r0 ? l.upd_r0 : l.c + 2;
                 s.per_comp = l.n_trmm + l.n_upd;
                 s.ntasks = s.per_comp * q;
                 s.k_off = l.has_special ? q : 0;
@@ -640,24 +777,31 @@ class DagBuilder {
                 s.J = l.J; s.pe = l.pe; s.c_lo = l.c_lo; s.c_hi = l.c_hi; s.tiles128 = l.tiles128; s.with_leaf = l.with_leaf;
                 std::vector<Access> a;
                 int nt;
-                if (l.t_count > 0) {
-                    // a sub-range of the tiles (column-major over the tile columns from c_lo on): the columns it touches
-                    const int u = l.tiles128 ? 2 : 1, nbt = nb / u;
+                const int u = l.tiles128 ? 2 : 1, nbt = nb / u;
+                const int rlo = l.r_lo / u, rhi = l.r_hi ? l.r_hi / u : nbt;
+                s.r_lo = l.r_lo; s.r_hi = l.r_hi;
+                if (l.t_count > 0 || l.r_lo || l.r_hi) {
+                    // tiles [t_first, t_first + t_count) of the region (column-major over the tile columns from c_lo on, in
+                    // column c the tile rows [max(c, r_lo), r_hi)): the blocks they touch, column by column
+                    const long total = region_tiles(l.c_lo / u, l.c_hi / u, rlo, rhi);
+                    const long first = l.t_count > 0 ? l.t_first : 0;
+                    long left = l.t_count > 0 ? l.t_count : total;
+                    nt = (int)left;
                     int c = l.c_lo / u;
-                    long t = l.t_first;
-                    while (t >= nbt - c) { t -= nbt - c; ++c; }
-                    long left = l.t_count;
-                    while (left > 0) {
-                        const long in_col = nbt - c - t;
+                    long t = first;
+                    auto col_tiles = [&](int cc) { const int lo = cc > rlo ? cc : rlo; return rhi > lo ? rhi - lo : 0; };
+                    while (c < l.c_hi / u && t >= col_tiles(c)) { t -= col_tiles(c); ++c; }
+                    while (left > 0 && c < l.c_hi / u) {
+                        const long in_col = col_tiles(c) - t;
                         const long take = left < in_col ? left : in_col;
-                        const int ra = c + (int)t, rb = ra + (int)take;
+                        const int ra = (c > rlo ? c : rlo) + (int)t, rb = ra + (int)take;
                         a.push_back({BUF_M, ra * u, rb * u, c * u, (c + 1) * u, true});
                         a.push_back({BUF_M, ra * u, rb * u, l.J, l.pe, false});
                         a.push_back({BUF_M, c * u, (c + 1) * u, l.J, l.pe, false});
                         left -= take; t = 0; ++c;
                     }
-                    nt = l.t_count;
-                    s.t_first = l.t_first; s.t_count = l.t_count;
+                    if (left > 0) { failed = true; return; }
+                    s.t_first = (int)first; s.t_count = nt;
                 } else {
                     nt = l.tiles128 ? trapezoid_tiles(nb / 2, l.c_lo / 2, l.c_hi / 2) + (l.with_leaf ? 1 : 0)
                                     : trapezoid_tiles(nb, l.c_lo, l.c_hi);
@@ -669,6 +813,41 @@ class DagBuilder {
                 s.ntasks = nt * q;
                 s.k_off = l.with_leaf ? q : 0;
                 push(s, a);
+            }
+            if (l.kind == L_TRI) {
+                DagSeg s = blank(S_TRI);
+                s.tiles128 = l.tiles128; s.tri_mb = l.tri_mb; s.tri_p0 = l.tri_p0; s.tri_np = l.tri_np; s.tri_w = l.tri_w;
+                s.per_comp = l.tri_np * l.tri_mb * l.tri_mb;
+                s.ntasks = s.per_comp * q; s.k_off = 0;
+                std::vector<Access> a;
+                const int u = l.tiles128 ? 2 : 1, mb = l.tri_mb * u;              // in 64-blocks
+                for (int pr = l.tri_p0; pr < l.tri_p0 + l.tri_np; ++pr) {
+                    const int C0 = 2 * pr * mb, R0 = C0 + mb;
+                    const int Re = R0 + mb < nb ? R0 + mb : nb;
+                    if (R0 >= nb) continue;
+                    if (l.tri_w == 0) {
+                        a.push_back({BUF_M, R0, Re, C0, R0, false});
+                        a.push_back({BUF_W, C0, R0, C0, R0, false});
+                        a.push_back({BUF_V, R0, Re, C0, R0, true});
+                    } else {
+                        a.push_back({BUF_W, R0, Re, R0, Re, false});
+                        a.push_back({BUF_V, R0, Re, C0, R0, false});
+                        a.push_back({BUF_W, R0, Re, C0, R0, true});
+                    }
+                }
+                push(s, a);
+            }
+            if (l.kind == L_PSOLVE) {
+                DagSeg s = blank(S_PSOLVE);
+                s.J = l.J; s.pe = l.pe; s.c_lo = l.c_lo; s.r_lo = l.r_lo; s.tiles128 = 1;
+                s.per_comp = (nb - l.r_lo) / 2;
+                s.ntasks = s.per_comp * q; s.k_off = 0;
+                std::vector<Access> a;
+                const int c0 = l.J + 2 * l.c_lo;                       // first 64-block column of the tile column
+                a.push_back({BUF_M, l.r_lo, nb, l.J, c0 + 2, false});
+                a.push_back({BUF_W, c0, c0 + 2, l.J, c0 + 2, false});
+                a.push_back({BUF_M, l.r_lo, nb, c0, c0 + 2, true});
+                if (s.ntasks > 0) push(s, a);
             }
             for (int i = 0; i < l.fs.njobs; ++i) {
                 const FillJob& jb = l.fs.job[i];
@@ -693,6 +872,8 @@ class DagBuilder {
         for (int i = 0; i < DAG_MAXDEP; ++i) { s.dep[i] = -1; s.need[i] = 0; }
         s.J = s.pe = s.c = s.diag_end = s.has_special = s.n_trmm = s.n_upd = 0;
         s.c_lo = s.c_hi = s.tiles128 = s.with_leaf = 0; s.t_first = s.t_count = 0;
+        s.r_lo = s.r_hi = s.trmm_r0 = s.upd_r0 = 0;
+        s.tri_mb = s.tri_p0 = s.tri_np = s.tri_w = 0;
         s.job.type = FILL_NONE; s.job.nblk = 0; s.job.t0 = 0; s.job.R0 = s.job.R1 = s.job.j0 = s.job.j1 = 0;
         s.job.kb0 = s.job.kb1 = 0;
         return s;
@@ -715,15 +896,25 @@ class DagBuilder {
 
     void step_access(std::vector<Access>& a, const Launch& l) const {
         const int c = l.c;
-        a.push_back({BUF_W, c, c + 1, c, c + 1, false});
-        if (c > l.J) a.push_back({BUF_M, c, nb, c - 1, c, false});            // L[c, c-1] and L[r, c-1]
-        a.push_back({BUF_M, c + 1, nb, c, c + 1, true});                     // the block column itself
-        const int de = l.diag_end < nb ? l.diag_end : nb;
-        for (int r = c + 1; r < de; ++r) a.push_back({BUF_M, r, r + 1, r, r + 1, true});
+        const int t0 = l.trmm_r0 ? l.trmm_r0 : c + 1, t1 = t0 + l.n_trmm;        // rows of the solve tiles
+        const int u0 = l.upd_r0 ? l.upd_r0 : c + 2, u1 = u0 + l.n_upd;          // rows of the delayed-update tiles
+        if (l.n_trmm > 0) {
+            a.push_back({BUF_W, c, c + 1, c, c + 1, false});
+            if (c > l.J) {
+                a.push_back({BUF_M, c, c + 1, c - 1, c, false});                  // L[c, c-1]
+                a.push_back({BUF_M, t0, t1, c - 1, c, false});                    // L[r, c-1]
+            }
+            a.push_back({BUF_M, t0, t1, c, c + 1, true});                        // the block column itself
+            const int de = l.diag_end < t1 ? l.diag_end : t1;
+            for (int r = t0; r < de; ++r) a.push_back({BUF_M, r, r + 1, r, r + 1, true});
+        }
         if (l.has_special) leaf_access(a, c + 1);
         if (l.n_upd > 0) {
-            a.push_back({BUF_M, c + 2, nb, c + 1, c + 2, true});
-            if (c > l.J) a.push_back({BUF_M, c + 1, nb, l.J, c, false});
+            a.push_back({BUF_M, u0, u1, c + 1, c + 2, true});
+            if (c > l.J) {
+                a.push_back({BUF_M, u0, u1, l.J, c, false});
+                a.push_back({BUF_M, c + 1, c + 2, l.J, c, false});
+            }
         }
     }
 

@@ -678,7 +678,7 @@ __global__ __launch_bounds__(256, 2) void leaf_kernel(T* __restrict__ M, T* __re
 //   MK : element (m, k) at P[m * ld + k]      KM : element (m, k) at P[k * ld + m]
 // and staged in LDS as [k][m] (KT = 16 k rows per stage, double buffered through registers).
 // ---------------------------------------------------------------------------------------------------
-enum GemmOp { OP_SYRK = 1, OP_TRTRI_T = 2, OP_TRTRI_W = 3, OP_LAUUM = 4, OP_PRED_U = 5 };
+enum GemmOp { OP_SYRK = 1, OP_TRTRI_T = 2, OP_TRTRI_W = 3, OP_LAUUM = 4, OP_PRED_U = 5, OP_PSOLVE = 6 };
 enum Lay { MK = 0, KM = 1 };
 
 struct GemmArgs {
@@ -691,6 +691,7 @@ struct GemmArgs {
     int t0;                                     // first tile of this launch (OP_SYRK: a launch may cover a sub-range)
     int skipq;                                  // OP_SYRK on 128-tiles: tile 0 leaves its top-left 64x64 quadrant alone
                                                 // (the diagonal block there is factored by the same launch, wide_leaf_kernel)
+    int r_lo = 0, r_hi = 0;                     // OP_SYRK: tile rows [max(column, r_lo), r_hi) of every tile column (r_hi = 0: to nb)
     const void* bvec = nullptr;                 // OP_LAUUM on 128-tiles: b (npad per component) and the partial buffer of
     double* part = nullptr;                     // z = A^-1 b, [component][tile][2][128]; null = no fused product
 };
@@ -823,8 +824,10 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, const int lin /*blo
         // M[r, c] -= sum_{kt in [p0, p1)} M[r, kt] M[c, kt]^T over the tiles c in [p2, p3), r in [c, nb)
         // (p3 == nb: the whole trailing triangle; p3 < nb: the rest of the current panel), column-major
         int t = bid + g.t0, c = g.p2;
-        while (t >= g.nb - c) { t -= g.nb - c; ++c; }
-        const int r = c + t;
+        const int rhi = g.r_hi ? g.r_hi : g.nb;
+        int rfirst = c > g.r_lo ? c : g.r_lo;
+        while (t >= rhi - rfirst) { t -= rhi - rfirst; ++c; rfirst = c > g.r_lo ? c : g.r_lo; }
+        const int r = rfirst + t;
         A0 = Ab + (size_t)r * TM * g.ldA + (size_t)g.p0 * TM; dA = TM;
         B0 = Bb + (size_t)c * TM * g.ldB + (size_t)g.p0 * TM; dB = TM;
         nkt = g.p1 - g.p0;
@@ -867,6 +870,17 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, const int lin /*blo
         nkt = g.nb - r;
         tri_b = r == c;
         Ct = Cb + (size_t)r * TM * g.ldC + (size_t)c * TM;
+    } else if constexpr (OP == OP_PSOLVE) {
+        // Panel solve of the rows below the chain rows (fill_sched.h: L_PSOLVE), in place in M:
+        //   L[R, c0 + jt] = sum_{kt = 0}^{jt} A[R, c0 + kt] W[c0 + jt, c0 + kt]^T      c0 = p0: first tile column of the panel,
+        // jt = p1, R = p2 + bid; W_PP = the panel's block of L^-1 (lower triangular: the last k tile is its diagonal tile).
+        // The tile it overwrites is its own last A operand: every global read of the k loop has been consumed through LDS
+        // before the loop's last barrier, the stores come after it.
+        const int R = g.p2 + bid, jt = g.p1, c0 = g.p0;
+        A0 = Ab + (size_t)R * TM * g.ldA + (size_t)c0 * TM; dA = TM;
+        B0 = Bb + (size_t)(c0 + jt) * TM * g.ldB + (size_t)c0 * TM; dB = TM;
+        nkt = jt + 1;
+        Ct = Cb + (size_t)R * TM * g.ldC + (size_t)(c0 + jt) * TM;
     } else {
         // OP_PRED_U: U[m, r] = sum_{kt = 0}^{r} X[m, kt] W[r, kt]^T    (X = scaled cross covariance, n0pad x npad)
         const int r = g.nb - 1 - bid / g.p0, m = bid % g.p0;       // p0 = row tiles of X; longest k loops (large r) first
@@ -915,7 +929,7 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, const int lin /*blo
     if constexpr (OP == OP_LAUUM) { dead_lo = tri_first; dead_hi = tri_first + (tri_b && wn0 > wm0 ? wn0 : wm0) / KT; }
     else if constexpr (OP == OP_TRTRI_T) { dead_lo = tri_first; dead_hi = tri_first + wn0 / KT; }
     else if constexpr (OP == OP_TRTRI_W) dead_lo = tri_first + (wm0 + WTM) / KT;
-    else if constexpr (OP == OP_PRED_U) dead_lo = tri_first + (wn0 + WTN) / KT;
+    else if constexpr (OP == OP_PRED_U || OP == OP_PSOLVE) dead_lo = tri_first + (wn0 + WTN) / KT;
     auto wave_live = [&](int sg) { return !HAS_TRI || sg < dead_lo || sg >= dead_hi; };
     auto compute_stage = [&](int buf) {
         const T* as = As + buf * KT * LD;
@@ -1290,8 +1304,10 @@ struct StepArgs {
                          // next panel's first diagonal block is factored by the trailing-update launch)
     int q;
     int has_special;     // tile (c+1, c) continues with the diagonal block c+1  (c + 1 < pe)
-    int n_trmm;          // TRMM tiles per component INCLUDING the special one: rows c+1 .. nb-1
-    int n_upd;           // delayed-update tiles per component
+    int n_trmm;          // TRMM tiles per component INCLUDING the special one: rows trmm_r0 .. trmm_r0 + n_trmm - 1
+    int n_upd;           // delayed-update tiles per component: rows upd_r0 .. upd_r0 + n_upd - 1
+    int trmm_r0, upd_r0; // c + 1 / c + 2 for a whole step; the persistent launch cuts a step into the rows the next diagonal
+                         // blocks need and the rows below (fill_sched.h: run_interleaved)
     double* logdet; int* info;
     FillSet fs;          // filler jobs (fs.nblk blocks)
 };
@@ -1455,7 +1471,7 @@ __device__ __forceinline__ void chain_step_body(const StepArgs& a, int b, unsign
     }
     if (t >= 0) {
         if (t == 0 && a.has_special) __builtin_amdgcn_s_setprio(3);   // the chain of the step shares its CU with other tiles
-        const int c = a.c, r = c + 1 + t;
+        const int c = a.c, r = a.trmm_r0 + t;
         T* Mk = (T*)a.M + (size_t)k * a.mat;
         const T* Wk = (const T*)a.W + (size_t)k * a.mat;
         T* Ct = Mk + (size_t)r * TS * ld + (size_t)c * TS;
@@ -1512,7 +1528,7 @@ __device__ __forceinline__ void chain_step_body(const StepArgs& a, int b, unsign
         k = b % a.q;
         t = b / a.q;
         const int cc = a.c + 1;
-        const int r = cc + 1 + t;
+        const int r = a.upd_r0 + t;
         T* Mk = (T*)a.M + (size_t)k * a.mat;
         T* Ct = Mk + (size_t)r * TS * ld + (size_t)cc * TS;
         typename TL::acc_t acc[2][2];
@@ -1683,6 +1699,7 @@ __global__ __launch_bounds__(256, 2) void dag_kernel(DagArgs a) {
             sa.M = a.M; sa.W = a.W; sa.mat = mat; sa.npad = npad; sa.nb = nbk;
             sa.c = sg.c; sa.J = sg.J; sa.pe = sg.pe; sa.diag_end = sg.diag_end; sa.q = q;
             sa.has_special = sg.has_special; sa.n_trmm = sg.n_trmm; sa.n_upd = sg.n_upd;
+            sa.trmm_r0 = sg.trmm_r0; sa.upd_r0 = sg.upd_r0;
             sa.logdet = a.logdet; sa.info = a.info;
             sa.fs.njobs = 0; sa.fs.nblk = 0;
             chain_step_body<T, WT>(sa, b, lds);
@@ -1697,14 +1714,40 @@ __global__ __launch_bounds__(256, 2) void dag_kernel(DagArgs a) {
                 g.q = q;
                 const int lin = b - (sg.with_leaf ? q : 0);
                 if (sg.tiles128) {
+                    g.r_lo = sg.r_lo / 2; g.r_hi = sg.r_hi / 2;
                     g.nb = nbk / 2; g.p0 = sg.J / 2; g.p1 = sg.pe / 2; g.p2 = sg.c_lo / 2; g.p3 = sg.c_hi / 2;
                     g.t0 = sg.t_first; g.skipq = sg.with_leaf;
                     gemm_body<T, OP_SYRK, 128, 4, WT>(g, lin, lds);
                 } else {
+                    g.r_lo = sg.r_lo; g.r_hi = sg.r_hi;
                     g.nb = nbk; g.p0 = sg.J; g.p1 = sg.pe; g.p2 = sg.c_lo; g.p3 = sg.c_hi;
                     g.t0 = sg.t_first + (sg.with_leaf ? 1 : 0); g.skipq = 0;
                     gemm_body<T, OP_SYRK, 64, 4, WT>(g, lin, lds);
                 }
+            }
+        } else if (sg.kind == lcgp_fill::S_PSOLVE) {
+            GemmArgs g;
+            g.sA = g.sB = g.sC = mat; g.ldA = g.ldB = g.ldC = npad;
+            g.A = a.M; g.B = a.W; g.C = a.M;
+            g.q = q; g.t0 = 0; g.skipq = 1; g.nb = npad / 128;
+            g.p0 = sg.J / 2; g.p1 = sg.c_lo; g.p2 = sg.r_lo / 2; g.p3 = 0;
+            gemm_body<T, OP_PSOLVE, 128, 4, WT>(g, b, lds);
+        } else if (sg.kind == lcgp_fill::S_TRI) {
+            // one step of one level of W = L^-1 for a run of pairs (do_trtri's launches, cut by the planner)
+            GemmArgs g;
+            g.sA = g.sB = g.sC = mat; g.ldA = g.ldB = g.ldC = npad;
+            g.q = q; g.t0 = 0; g.skipq = 1;          // (skipq: no grid-shaped re-enumeration of the tiles here)
+            g.p0 = sg.tri_mb; g.p1 = sg.tri_np; g.p2 = sg.tri_p0; g.p3 = 0;
+            if (sg.tri_w == 0) { g.A = a.M; g.B = a.W; g.C = a.V; }
+            else { g.A = a.W; g.B = a.V; g.C = a.W; }
+            if (sg.tiles128) {
+                g.nb = npad / 128;
+                if (sg.tri_w == 0) gemm_body<T, OP_TRTRI_T, 128, 4, WT>(g, b, lds);
+                else gemm_body<T, OP_TRTRI_W, 128, 4, WT>(g, b, lds);
+            } else {
+                g.nb = nbk;
+                if (sg.tri_w == 0) gemm_body<T, OP_TRTRI_T, 64, 4, WT>(g, b, lds);
+                else gemm_body<T, OP_TRTRI_W, 64, 4, WT>(g, b, lds);
             }
         } else {
             FillSet fs;
@@ -1738,7 +1781,7 @@ __global__ __launch_bounds__(256, 2) void dag_kernel(DagArgs a) {
                 unsigned xcc;
                 asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
                 tr[0] = tr0; tr[1] = tr1; tr[2] = tr2;
-                tr[3] = __builtin_amdgcn_s_memrealtime() | ((unsigned long long)(xcc & 15) << 60) | ((unsigned long long)seg << 44);
+                tr[3] = (__builtin_amdgcn_s_memrealtime() & ((1ull << 44) - 1)) | ((unsigned long long)(xcc & 15) << 60) | ((unsigned long long)seg << 44);
             }
 #endif
         }
@@ -2388,7 +2431,7 @@ int launch_fill(hipStream_t st, const FillSet& fs) {
 // trailing update with the panel [J, pe) of the tile columns [c_lo, c_hi) (64-block units, all rows below)
 template <typename T>
 int potrf_trailing(hipStream_t st, const Ws& w, int J, int pe, int c_lo, int c_hi, bool tiles128, bool with_leaf,
-                   int t_first = 0, int t_count = 0) {
+                   int t_first = 0, int t_count = 0, int r_lo = 0, int r_hi = 0) {
     if (c_lo >= c_hi) return 0;
     T* M = (T*)(w.base + w.off_M);
     GemmArgs g;
@@ -2400,7 +2443,7 @@ int potrf_trailing(hipStream_t st, const Ws& w, int J, int pe, int c_lo, int c_h
         g.nb = w.nb / 2; g.p0 = J / 2; g.p1 = pe / 2; g.p2 = c_lo / 2; g.p3 = c_hi / 2;
         const int nt = t_count > 0 ? t_count : trapezoid_tiles(w.nb / 2, c_lo / 2, c_hi / 2);
         if (t_count > 0) {       // a sub-range of the update's tiles (the interleaved order of the persistent launch)
-            g.q = w.q; g.t0 = t_first; g.skipq = 0;
+            g.q = w.q; g.t0 = t_first; g.skipq = 0; g.r_lo = r_lo / 2; g.r_hi = r_hi / 2;
             hipLaunchKernelGGL((tile_gemm<T, OP_SYRK, 128, 8>), dim3((unsigned)nt * w.q), dim3(512), 0, st, g);
             CHECK_LAUNCH("tile_gemm");
             return 0;
@@ -2418,7 +2461,7 @@ int potrf_trailing(hipStream_t st, const Ws& w, int J, int pe, int c_lo, int c_h
     g.nb = w.nb; g.p0 = J; g.p1 = pe; g.p2 = c_lo; g.p3 = c_hi;
     const int nt = t_count > 0 ? t_count : trapezoid_tiles(w.nb, c_lo, c_hi);
     if (t_count > 0) {
-        g.q = w.q; g.t0 = t_first; g.skipq = 0;
+        g.q = w.q; g.t0 = t_first; g.skipq = 0; g.r_lo = r_lo; g.r_hi = r_hi;
         hipLaunchKernelGGL((tile_gemm<T, OP_SYRK, 64, 4>), dim3((unsigned)nt * w.q), dim3(256), 0, st, g);
         CHECK_LAUNCH("tile_gemm");
         return 0;
@@ -2459,6 +2502,11 @@ inline lcgp_fill::PlanParams plan_params(int dtype, int nb, int q, bool with_inv
     pp.syrk_small_tiles = sc.syrk_small_tiles; pp.fill_leaf = sc.fill_leaf; pp.fill_step = sc.fill_step;
     pp.leaf_in_wide = sc.leaf_in_wide;
     pp.interleaved = sc.dag == 2;
+    pp.with_trtri = pp.interleaved && with_inverse;
+    {
+        const int nb2 = nb / 2;
+        pp.trtri_all_small = (long long)q * (nb2 * (nb2 + 1) / 2) < sc.trtri_small_tiles ? 1 : 0;
+    }
     bool prog = false;
     if (!pp.interleaved && with_inverse && sc.progressive_tiles > 0 && pp.ob >= 2 && (pp.ob & (pp.ob - 1)) == 0) {
         const int nb2 = nb / 2;
@@ -2467,7 +2515,7 @@ inline lcgp_fill::PlanParams plan_params(int dtype, int nb, int q, bool with_inv
     pp.progressive = prog;
     pp.far_rides = !(pp.progressive && sc.progressive_far == 0);
     pp.with_dupd = nb <= sc.progressive_lauum;
-    if (inverse_done) *inverse_done = pp.progressive ? (pp.with_dupd ? 2 : 1) : 0;
+    if (inverse_done) *inverse_done = pp.progressive ? (pp.with_dupd ? 2 : 1) : (pp.with_trtri ? 1 : 0);
     return pp;
 }
 
@@ -2599,6 +2647,8 @@ int do_potrf(hipStream_t st, const Ws& w, const lcgp_sched& sc, bool stats_zeroe
                 a.M = M; a.W = W; a.mat = w.mat; a.npad = w.npad; a.nb = w.nb;
                 a.c = l.c; a.J = l.J; a.pe = l.pe; a.q = w.q;
                 a.diag_end = l.diag_end; a.has_special = l.has_special; a.n_trmm = l.n_trmm; a.n_upd = l.n_upd;
+                a.trmm_r0 = l.trmm_r0 ? l.trmm_r0 : l.c + 1;
+                a.upd_r0 = l.upd_r0 ? l.upd_r0 : l.c + 2;
                 a.logdet = logdet; a.info = info;
                 a.fs = fs;
                 const long nblk = (long)(a.n_trmm + a.n_upd) * w.q + fs.nblk;
@@ -2607,8 +2657,39 @@ int do_potrf(hipStream_t st, const Ws& w, const lcgp_sched& sc, bool stats_zeroe
                 break;
             }
             case lcgp_fill::L_TRAIL:
-                rc = potrf_trailing<T>(st, w, l.J, l.pe, l.c_lo, l.c_hi, l.tiles128 != 0, l.with_leaf != 0, l.t_first, l.t_count);
+                rc = potrf_trailing<T>(st, w, l.J, l.pe, l.c_lo, l.c_hi, l.tiles128 != 0, l.with_leaf != 0, l.t_first, l.t_count, l.r_lo, l.r_hi);
                 break;
+            case lcgp_fill::L_PSOLVE: {
+                GemmArgs g;
+                g.sA = g.sB = g.sC = w.mat; g.ldA = g.ldB = g.ldC = w.npad;
+                g.A = M; g.B = W; g.C = M;
+                g.q = w.q; g.t0 = 0; g.skipq = 1; g.nb = w.npad / 128;
+                g.p0 = l.J / 2; g.p1 = l.c_lo; g.p2 = l.r_lo / 2; g.p3 = 0;
+                const int nt = (w.nb - l.r_lo) / 2;
+                if (nt > 0) hipLaunchKernelGGL((tile_gemm<T, OP_PSOLVE, 128, 8>), dim3((unsigned)nt * w.q), dim3(512), 0, st, g);
+                CHECK_LAUNCH("tile_gemm");
+                break;
+            }
+            case lcgp_fill::L_TRI: {
+                GemmArgs g;
+                g.sA = g.sB = g.sC = w.mat; g.ldA = g.ldB = g.ldC = w.npad;
+                g.p0 = l.tri_mb; g.p1 = l.tri_np; g.p2 = l.tri_p0; g.p3 = 0;
+                if (l.tri_w == 0) { g.A = M; g.B = W; g.C = w.base + w.off_V; }
+                else { g.A = W; g.B = w.base + w.off_V; g.C = W; }
+                const int nt = l.tri_np * l.tri_mb * l.tri_mb;
+                g.q = w.q; g.t0 = 0; g.skipq = 1;
+                if (l.tiles128) {
+                    g.nb = w.npad / 128;
+                    if (l.tri_w == 0) hipLaunchKernelGGL((tile_gemm<T, OP_TRTRI_T, 128, 8>), dim3((unsigned)nt * w.q), dim3(512), 0, st, g);
+                    else hipLaunchKernelGGL((tile_gemm<T, OP_TRTRI_W, 128, 8>), dim3((unsigned)nt * w.q), dim3(512), 0, st, g);
+                } else {
+                    g.nb = w.nb;
+                    if (l.tri_w == 0) hipLaunchKernelGGL((tile_gemm<T, OP_TRTRI_T, 64, 4>), dim3((unsigned)nt * w.q), dim3(256), 0, st, g);
+                    else hipLaunchKernelGGL((tile_gemm<T, OP_TRTRI_W, 64, 4>), dim3((unsigned)nt * w.q), dim3(256), 0, st, g);
+                }
+                CHECK_LAUNCH("tile_gemm");
+                break;
+            }
             default:
                 rc = launch_fill<T>(st, fs);
         }

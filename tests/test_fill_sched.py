@@ -24,34 +24,35 @@ def dump_plan(tmp_path_factory):
                     os.path.join(ROOT, 'tests', 'native', 'dump_plan.cpp')], check=True)
 
     def run(nb, q, ob, syrk_small=2000, fill_leaf=248, fill_step=248, leaf_in_wide=1024, progressive=1, far_rides=1, with_dupd=1,
-            dag=0, interleaved=0):
+            dag=0, interleaved=0, with_trtri=0, trtri_all_small=0):
         out = subprocess.run([exe] + [str(v) for v in (nb, q, ob, syrk_small, fill_leaf, fill_step, leaf_in_wide, progressive,
-                                                       far_rides, with_dupd, dag, interleaved)],
+                                                       far_rides, with_dupd, dag, interleaved, with_trtri, trtri_all_small)],
                              check=True, capture_output=True, text=True).stdout
         assert 'FAILED' not in out
         launches = []
         segs = []
         for line in out.splitlines():
             f = line.split()
-            if f[0] == 'S':
-                v = [int(x) for x in f[1:29]]
-                keys = ('kind t0 ntasks per_comp k_off J pe c diag_end has_special n_trmm n_upd c_lo c_hi tiles128 with_leaf '
-                        'type nblk jt0 R0 R1 j0 j1 kb0 kb1 t_first t_count ndeps').split()
-                sg = dict(zip(keys, v))
-                sg['deps'] = [tuple(int(y) for y in x.split(':')) for x in f[29:]]
-                assert len(sg['deps']) == sg['ndeps']
-                sg['jobs'] = [dict(type=sg['type'], nblk=sg['nblk'], t0=sg['jt0'], R0=sg['R0'], R1=sg['R1'], j0=sg['j0'],
-                                   j1=sg['j1'], kb0=sg['kb0'], kb1=sg['kb1'])] if sg['kind'] == 4 else []
-                segs.append(sg)
-                continue
-            v = [int(x) for x in f[1:]]
+            d = {}
+            deps = []
+            for kv in f[1:]:
+                k, _, v = kv.partition('=')
+                if k == 'deps':
+                    deps = [tuple(int(y) for y in x.split(':')) for x in v.split(',') if x]
+                else:
+                    d[k] = int(v)
             if f[0] == 'L':
-                launches.append(dict(kind=v[0], J=v[1], pe=v[2], c=v[3], diag_end=v[4], has_special=v[5], n_trmm=v[6],
-                                     n_upd=v[7], c_lo=v[8], c_hi=v[9], tiles128=v[10], with_leaf=v[11], nblk=v[13],
-                                     t_first=v[14], t_count=v[15], jobs=[]))
+                d['jobs'] = []
+                launches.append(d)
+            elif f[0] == 'J':
+                d['t0'] = d.pop('jt0')
+                launches[-1]['jobs'].append(d)
             else:
-                launches[-1]['jobs'].append(dict(type=v[0], nblk=v[1], t0=v[2], R0=v[3], R1=v[4], j0=v[5], j1=v[6],
-                                                 kb0=v[7], kb1=v[8]))
+                assert len(deps) == d['ndeps']
+                d['deps'] = deps
+                d['jobs'] = [dict(type=d['type'], nblk=d['nblk'], t0=d['jt0'], R0=d['R0'], R1=d['R1'], j0=d['j0'], j1=d['j1'],
+                                  kb0=d['kb0'], kb1=d['kb1'])] if d['kind'] == 4 else []
+                segs.append(d)
         return (launches, segs) if dag else launches
     return run
 
@@ -119,8 +120,14 @@ class Replay:
 
     def run_step(self, l):
         nb, c, J = self.nb, l['c'], l['J']
-        assert l['n_trmm'] == nb - 1 - c
-        for r in range(c + 1, nb):
+        t0 = l.get('trmm_r0') or c + 1          # first block row of the solve tiles / of the delayed-update tiles
+        u0 = l.get('upd_r0') or c + 2
+        if not l.get('trmm_r0'):
+            assert l['n_trmm'] == nb - 1 - c
+        assert t0 + l['n_trmm'] <= nb and u0 + l['n_upd'] <= nb
+        if l['has_special']:
+            assert t0 == c + 1
+        for r in range(t0, t0 + l['n_trmm']):
             self.new_item()
             tile = self.rd('M', r, r + 1, c, c + 1).copy()
             if c > J:
@@ -134,8 +141,9 @@ class Replay:
                 else:
                     self.wr('M', r, r, D)
         if l['n_upd']:
-            assert l['n_upd'] == nb - (c + 1) - 1
-            for r in range(c + 2, nb):
+            if not l.get('upd_r0'):
+                assert l['n_upd'] == nb - (c + 1) - 1
+            for r in range(u0, u0 + l['n_upd']):
                 self.new_item()
                 t = self.rd('M', r, r + 1, c + 1, c + 2).copy()
                 for j in range(J, c):
@@ -144,16 +152,20 @@ class Replay:
 
     def run_trail(self, l):
         J, pe = l['J'], l['pe']
-        if l.get('t_count', 0):
-            # a sub-range [t_first, t_first + t_count) of the tiles, column-major from tile column c_lo on (gemm_body, OP_SYRK);
-            # on 128x128 tiles a tile is 2 x 2 blocks (the diagonal ones hold 3)
+        if l.get('t_count', 0) or l.get('r_lo', 0) or l.get('r_hi', 0):
+            # tiles [t_first, t_first + t_count) of a region: column-major over the tile columns [c_lo, c_hi), in column C the
+            # tile rows [max(C, r_lo), r_hi) (gemm_body, OP_SYRK); on 128x128 tiles a tile is 2 x 2 blocks (3 on the diagonal)
             u = 2 if l['tiles128'] else 1
             nbt = self.nb // u
+            rlo, rhi = l.get('r_lo', 0) // u, (l.get('r_hi', 0) // u) or nbt
             tiles = []
-            for C in range(l['c_lo'] // u, nbt):
-                for r in range(C, nbt):
+            for C in range(l['c_lo'] // u, l['c_hi'] // u):
+                for r in range(max(C, rlo), rhi):
                     tiles.append((r, C))
-            for r, C in tiles[l['t_first']:l['t_first'] + l['t_count']]:
+            cnt = l.get('t_count', 0) or len(tiles)
+            first = l.get('t_first', 0)
+            assert first + cnt <= len(tiles)
+            for r, C in tiles[first:first + cnt]:
                 self.new_item()
                 for cc in range(C * u, (C + 1) * u):
                     for rr in range(max(r * u, cc), (r + 1) * u):
@@ -236,6 +248,40 @@ class Replay:
                             acc += self.rd('W', R0 + rl, R0 + rl + 1, R0 + kt, R0 + kt + 1) @ self.rd('V', R0 + kt, R0 + kt + 1, C0 + cl, C0 + cl + 1)
                         self.wr('W', R0 + rl, C0 + cl, -acc)
 
+    def run_tri(self, l):
+        """one step of one level of the triangular inverse for the pairs [tri_p0, tri_p0 + tri_np): tiles of `u` blocks"""
+        u = 2 if l['tiles128'] else 1
+        mb, nbt = l['tri_mb'], self.nb // u
+        for pr in range(l['tri_p0'], l['tri_p0'] + l['tri_np']):
+            C0 = 2 * pr * mb
+            R0 = C0 + mb
+            for rl in range(mb):
+                for cl in range(mb):
+                    self.new_item()
+                    if R0 + rl >= nbt:
+                        continue
+                    r, c = (R0 + rl) * u, (C0 + cl) * u
+                    acc = np.zeros((TS * u, TS * u))
+                    if l['tri_w'] == 0:
+                        for kt in range(cl, mb):
+                            k = (C0 + kt) * u
+                            acc += self.rd('M', r, r + u, k, k + u) @ self.rd('W', k, k + u, c, c + u)
+                        self.wr('V', r, c, acc)
+                    else:
+                        for kt in range(0, rl + 1):
+                            k = (R0 + kt) * u
+                            acc += self.rd('W', r, r + u, k, k + u) @ self.rd('V', k, k + u, c, c + u)
+                        self.wr('W', r, c, -acc)
+
+    def run_psolve(self, l):
+        """rows from block row r_lo on: L[R, jt] = sum_{kt <= jt} A[R, kt] W_PP[jt, kt]^T on 128 x 128 tiles (2 x 2 blocks)"""
+        J, jt = l['J'], l['c_lo']
+        c0 = J + 2 * jt
+        for R in range(l['r_lo'] // 2, self.nb // 2):
+            self.new_item()
+            v = self.rd('M', 2 * R, 2 * R + 2, J, c0 + 2) @ self.rd('W', c0, c0 + 2, J, c0 + 2).T
+            self.wr('M', 2 * R, c0, v)
+
     def run(self, launches):
         for l in launches:
             self.begin_launch()
@@ -245,6 +291,10 @@ class Replay:
                 self.run_step(l)
             elif l['kind'] == 3:
                 self.run_trail(l)
+            elif l['kind'] == 5:
+                self.run_tri(l)
+            elif l['kind'] == 6:
+                self.run_psolve(l)
             self.run_jobs(l)
             self.end_launch()
 
@@ -296,14 +346,18 @@ class DagReplay(Replay):
                 self.run_step(sg)
             elif sg['kind'] == 3:
                 self.run_trail(sg)
+            elif sg['kind'] == 5:
+                self.run_tri(sg)
+            elif sg['kind'] == 6:
+                self.run_psolve(sg)
             else:
                 self.run_jobs(sg)
             self.end_launch()
             nitems = self.item
-            if sg['kind'] == 3 and sg['tiles128']:
+            if sg['kind'] == 3 and sg['tiles128'] and not (sg['t_count'] or sg['r_lo'] or sg['r_hi']):
                 # the kernel works on 128x128 tiles there (4 blocks, 3 on the diagonal, per task): same blocks, fewer tasks
                 nitems = sg['per_comp']
-            if sg['kind'] != 4 or sg['type'] < 5:     # (a task of a block-inverse level may fall outside the matrix)
+            if sg['kind'] not in (4, 5) or (sg['kind'] == 4 and sg['type'] < 5):     # (a task of a block-inverse level may fall outside the matrix)
                 assert nitems == sg['per_comp'], (i, sg, nitems)
             rset = {(b, r, c) for _, b, r, c in self.reads}
             for key in rset:
@@ -431,4 +485,30 @@ def test_interleaved_order_for_the_persistent_launch(dump_plan, nb, q, ob, kw):
     for i, sg in enumerate(segs):
         if sg['kind'] in (1, 2):
             for d, _ in sg['deps']:
-                assert not (kinds[d]['kind'] == 3 and kinds[d]['t_count'] > 0 and kinds[d]['c_lo'] > sg['pe']), (i, sg, kinds[d])
+                assert not (kinds[d]['kind'] == 3 and kinds[d]['c_lo'] > sg['pe']), (i, sg, kinds[d])
+    # ... and the chain part of a step never waits for the bulk part of another
+    for i, sg in enumerate(segs):
+        if sg['kind'] == 2 and sg['has_special']:
+            for d, _ in sg['deps']:
+                assert not (kinds[d]['kind'] == 2 and kinds[d]['trmm_r0'] > kinds[d]['c'] + 1), (i, sg, kinds[d])
+
+
+@pytest.mark.parametrize('nb,q,ob,kw', [(64, 8, 4, {}), (64, 1, 4, {}), (64, 2, 4, {}), (16, 4, 4, {}), (32, 6, 4, {}), (18, 1, 4, {}),
+                                        (10, 3, 4, {}), (6, 1, 4, {}), (4, 1, 4, {}), (2, 1, 4, {}), (24, 2, 8, {}), (20, 1, 8, {}),
+                                        (12, 1, 2, {}), (14, 2, 6, {}), (16, 1, 3, {}), (32, 2, 4, dict(trtri_all_small=1)),
+                                        (22, 3, 4, dict(trtri_all_small=1)), (64, 4, 4, dict(syrk_small=100))])
+def test_interleaved_order_with_the_triangular_inverse(dump_plan, nb, q, ob, kw):
+    """the factorisation AND W = L^-1 as one sequence: the early levels of the inverse ride on the chain-bound end of the
+    factorisation, the rest follows; replayed as a launch list and as a task graph"""
+    launches, segs = dump_plan(nb, q, ob, progressive=0, dag=1, interleaved=1, with_trtri=1, **kw)
+    assert any(l['kind'] == 5 for l in launches) or nb < 2
+    r = Replay(nb, q, seed=11 * nb + q)
+    r.run(launches)
+    r.check(inverse=True, ainv=False)
+    r = DagReplay(nb, q, seed=11 * nb + q)
+    assert r.run_dag(segs) <= 16
+    r.check(inverse=True, ainv=False)
+    # no step of the factorisation waits for a unit of the inverse
+    for i, sg in enumerate(segs):
+        if sg['kind'] in (1, 2, 3):
+            assert all(segs[d]['kind'] != 5 for d, _ in sg['deps']), (i, sg)

@@ -70,18 +70,26 @@ def main():
     segsz = (nbytes - off_seg) // max(nseg, 1)
     # sizeof(DagSeg): derive from the table span (padded to 256): use the known layout instead
     import struct
-    seg_ints = 6 + 16 + 16 + 7 + 4 + 2 + 9     # kind,t0,ntasks,per_comp,k_off,ndeps | dep | need | J.. | c_lo.. | t_first,t_count | job
+    seg_ints = 6 + 16 + 16 + 7 + 4 + 2 + 4 + 4 + 9     # kind,t0,ntasks,per_comp,k_off,ndeps | dep | need | J.. | c_lo.. | t_first,t_count | r_lo,r_hi,trmm_r0,upd_r0 | job
     kinds = []
     for i in range(nseg):
         b = host[off_seg + i * seg_ints * 4: off_seg + (i + 1) * seg_ints * 4].tobytes()
         v = struct.unpack('%di' % seg_ints, b)
-        kinds.append((v[0], v[38 + 7], v[38 + 8], v[38 + 9]))     # kind, c_lo, c_hi, tiles128
-    names = {1: 'leaf', 2: 'step', 3: 'trail', 4: 'fill'}
+        assert 1 <= v[0] <= 6, v[:8]
+        kinds.append((v[0], v[38 + 7], v[38 + 8], v[38 + 9], v[38 + 4], v[53]))     # kind, c_lo, c_hi, tiles128, has_special, trmm_r0
+    names = {1: 'leaf', 2: 'step', 3: 'trail', 4: 'fill', 5: 'tri', 6: 'psolve'}
+    cs = []
+    for i in range(nseg):
+        b = host[off_seg + i * seg_ints * 4: off_seg + (i + 1) * seg_ints * 4].tobytes()
+        cs.append(struct.unpack('%di' % seg_ints, b)[38 + 2])
+
+    def seg_c(si):
+        return cs[si]
     print('tasks %d, segments %d, span %.1f us, workgroup slots %d' % (nt, nseg, span, len(np.unique(np.round(t_take, 2)))))
     rows = {}
     for i in range(nt):
         kd = kinds[seg[i]]
-        key = names[kd[0]] + ('128' if kd[0] == 3 and kd[3] else '')
+        key = names[kd[0]] + ('128' if kd[0] in (3, 5) and kd[3] else '') + ('-chain' if kd[0] == 2 and kd[5] <= seg_c(seg[i]) + 1 else '')
         r = rows.setdefault(key, [0, 0.0, 0.0, 0.0])
         r[0] += 1
         r[1] += t_ready[i] - t_take[i]
