@@ -22,6 +22,7 @@
 #define LCGP_FILL_SCHED_H
 
 #include <stddef.h>
+#include <utility>
 #include <vector>
 
 namespace lcgp_fill {
@@ -1023,6 +1024,126 @@ class DagBuilder {
             }
         }
     }
+};
+
+// ---------------------------------------------------------------------------------------------------
+// The ORDER of the one task sequence (dag_kernel takes the tasks in sequence order; a task that is not ready blocks the
+// workgroup that took it, so the order decides how much of the chip waits).  The graph is scheduled on the host the way
+// the GPU will run it: a list schedule on `slots` workgroup slots with estimated task durations, always giving a free slot
+// the ready segment with the longest path to the end of the graph (the chain of diagonal blocks first, update tiles and
+// the inverse as filling).  The order in which the simulation STARTS tasks is the sequence: runs (segment, first task,
+// count).  A run only follows runs of everything its segment depends on, because a segment becomes ready in the
+// simulation only after all tasks of its dependencies have started AND ended -- so the in-order argument of dag_kernel
+// (the earliest unfinished task can always run) holds for any durations, right or wrong; wrong estimates cost waiting,
+// never correctness.  Counters stay per (segment, component): the runs of a segment share them.
+// ---------------------------------------------------------------------------------------------------
+struct DagRun {
+    int seg;       // segment
+    int b0, n;     // its tasks [b0, b0 + n)
+    int t0;        // position of the run's first task in the sequence
+};
+
+inline double seg_task_us(const DagSeg& s, int ob) {
+    switch (s.kind) {
+        case S_LEAF: return 17.0;
+        case S_STEP: return s.has_special ? 22.0 : 12.0;
+        case S_TRAIL: return (s.tiles128 ? 62.0 : 21.0) * (s.pe - s.J) / 4.0 + (s.with_leaf ? 10.0 : 0.0);
+        case S_PSOLVE: return 35.0 * (s.c_lo + 1);
+        case S_TRI: return s.tiles128 ? 10.0 + 35.0 * (s.tri_mb + 1) * 0.5 : 4.0 + 3.0 * (s.tri_mb + 1) * 0.5;
+        default: return 25.0 * (s.job.kb1 - s.job.kb0 > 0 ? (s.job.kb1 - s.job.kb0) / 4.0 : 1.0);
+    }
+    (void)ob;
+}
+
+class DagScheduler {
+ public:
+    std::vector<DagRun> runs;
+
+    // segs: in any order consistent with their dependency lists (DagBuilder's).  slots: resident workgroups.
+    void run(const std::vector<DagSeg>& segs, int slots, int ob) {
+        const int ns = (int)segs.size();
+        std::vector<double> dur(ns), bl(ns, 0.0);
+        std::vector<std::vector<int>> succ(ns);
+        std::vector<int> ndep(ns, 0);
+        for (int i = 0; i < ns; ++i) {
+            dur[i] = seg_task_us(segs[i], ob);
+            ndep[i] = segs[i].ndeps;
+            for (int d = 0; d < segs[i].ndeps; ++d) succ[segs[i].dep[d]].push_back(i);
+        }
+        // bottom level: the longest chain of task durations from the segment to the end (a segment with more tasks than
+        // slots counts its rounds)
+        for (int i = ns - 1; i >= 0; --i) {
+            double m = 0.0;
+            for (int j : succ[i]) if (bl[j] > m) m = bl[j];
+            const double rounds = (double)((segs[i].ntasks + slots - 1) / slots);
+            bl[i] = m + dur[i] * (rounds > 1.0 ? rounds : 1.0);
+        }
+        std::vector<int> next(ns, 0), done(ns, 0);
+        std::vector<int> ready;                       // indices of ready segments with tasks left
+        for (int i = 0; i < ns; ++i) if (ndep[i] == 0) ready.push_back(i);
+        struct Ev { double t; int seg, n; };
+        std::vector<Ev> heap;                         // min-heap on t
+        auto hpush = [&](Ev e) {
+            heap.push_back(e);
+            size_t i = heap.size() - 1;
+            while (i > 0 && heap[(i - 1) / 2].t > heap[i].t) { std::swap(heap[(i - 1) / 2], heap[i]); i = (i - 1) / 2; }
+        };
+        auto hpop = [&]() {
+            Ev top = heap[0];
+            heap[0] = heap.back();
+            heap.pop_back();
+            size_t i = 0;
+            for (;;) {
+                size_t l = 2 * i + 1, r = l + 1, m = i;
+                if (l < heap.size() && heap[l].t < heap[m].t) m = l;
+                if (r < heap.size() && heap[r].t < heap[m].t) m = r;
+                if (m == i) break;
+                std::swap(heap[m], heap[i]);
+                i = m;
+            }
+            return top;
+        };
+        double now = 0.0;
+        int free_slots = slots, t0 = 0;
+        long left = 0;
+        for (int i = 0; i < ns; ++i) left += segs[i].ntasks;
+        while (left > 0) {
+            // hand the free slots to the ready segments, longest remaining path first
+            while (free_slots > 0 && !ready.empty()) {
+                int bi = 0;
+                for (int i = 1; i < (int)ready.size(); ++i)
+                    if (bl[ready[i]] > bl[ready[bi]] || (bl[ready[i]] == bl[ready[bi]] && ready[i] < ready[bi])) bi = i;
+                const int s = ready[bi];
+                int m = segs[s].ntasks - next[s];
+                if (m > free_slots) m = free_slots;
+                if (!runs.empty() && runs.back().seg == s && runs.back().b0 + runs.back().n == next[s]) runs.back().n += m;
+                else runs.push_back({s, next[s], m, t0});
+                t0 += m;
+                hpush({now + dur[s], s, m});
+                next[s] += m;
+                free_slots -= m;
+                left -= m;
+                if (next[s] >= segs[s].ntasks) { ready[bi] = ready.back(); ready.pop_back(); }
+            }
+            if (left <= 0) break;
+            if (heap.empty()) { failed = true; return; }       // (a cycle or a dangling dependency: cannot happen for a DagBuilder graph)
+            // advance to the next completion (and everything that ends at the same time)
+            const double t = heap[0].t;
+            now = t;
+            while (!heap.empty() && heap[0].t <= t) {
+                const Ev e = hpop();
+                free_slots += e.n;
+                done[e.seg] += e.n;
+                if (done[e.seg] >= segs[e.seg].ntasks)
+                    for (int j : succ[e.seg])
+                        if (--ndep[j] == 0) ready.push_back(j);
+            }
+        }
+        makespan_us = now;
+        while (!heap.empty()) { const Ev e = hpop(); if (e.t > makespan_us) makespan_us = e.t; }
+    }
+    bool failed = false;
+    double makespan_us = 0.0;
 };
 
 }  // namespace lcgp_fill

@@ -1608,6 +1608,7 @@ struct DagArgs {
     void* M; void* W; void* V; size_t mat; int npad, nb, q;
     double* logdet; int* info;
     const DagSeg* segs; int nseg; int ntasks;
+    const lcgp_fill::DagRun* runs; int nruns;       // the order of the sequence: runs of (segment, first task, count)
     int* ctl;
     unsigned spin_limit;
     int flags;          // lcgp_sched.dag_flags
@@ -1626,8 +1627,9 @@ __global__ __launch_bounds__(256, 2) void dag_kernel(DagArgs a) {
     __shared__ int sh_task;
     const int tid = threadIdx.x;
     const DagSeg* __restrict__ segs = a.segs;
+    const lcgp_fill::DagRun* __restrict__ runs = a.runs;
     int* cnt = a.ctl + DAG_CTL;
-    int seg = 0, memo_seg = -1, memo_k = -1;
+    int run = 0, memo_seg = -1, memo_k = -1;
     if (tid == 0) sh_task = __hip_atomic_fetch_add(&a.ctl[0], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     for (;;) {
         // The task id was written to LDS by lane 0 at the END of the previous iteration.  The wait for that write is
@@ -1642,18 +1644,25 @@ __global__ __launch_bounds__(256, 2) void dag_kernel(DagArgs a) {
         unsigned long long tr0 = 0, tr1 = 0, tr2 = 0;
         if (tid == 0) tr0 = __builtin_amdgcn_s_memrealtime();
 #endif
-        while (t >= segs[seg].t0 + segs[seg].ntasks) ++seg;
+        while (t >= runs[run].t0 + runs[run].n) ++run;
+        const int seg = runs[run].seg;
         const DagSeg& sg = segs[seg];
-        const int b = t - sg.t0;
+        const int b = runs[run].b0 + (t - runs[run].t0);
         const int k = b < sg.k_off ? b : (b - sg.k_off) % a.q;
         if (seg != memo_seg || k != memo_k || (a.flags & 1)) {
             // (a workgroup that has already waited for this segment and component has seen everything they depend on)
             if (tid < sg.ndeps) {
                 const int* c = cnt + (size_t)sg.dep[tid] * a.q + k;
                 const int need = sg.need[tid];
+                // poll with a back-off: hundreds of workgroups may hold tasks far ahead of the chain, and their polls are
+                // memory traffic the chain's own (latency-bound) loads queue behind; a task of the chain itself keeps polling fast
+                const bool urgent = sg.kind == lcgp_fill::S_LEAF || (sg.kind == lcgp_fill::S_STEP && sg.has_special) ||
+                                    (sg.kind == lcgp_fill::S_TRAIL && !sg.tiles128 && sg.r_hi != 0);
                 unsigned it = 0;
                 while (dag_load(c) < need) {
-                    __builtin_amdgcn_s_sleep(4);
+                    if (urgent || it < 4) __builtin_amdgcn_s_sleep(2);
+                    else if (it < 32) __builtin_amdgcn_s_sleep(16);
+                    else __builtin_amdgcn_s_sleep(64);
                     ++it;
                     if (it > a.spin_limit || ((it & 255u) == 0 && dag_load(&a.ctl[1]) != 0)) {
                         __hip_atomic_store(&a.ctl[1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -2492,7 +2501,9 @@ struct PlanHeader {
     int inverse_done;          // what the plan leaves behind the factorisation: 0 = L, 1 = and L^-1, 2 = and A^-1
     int num_cu;
     lcgp_sched sched;
-    size_t off_launch, off_seg, bytes;
+    int nruns;
+    double sim_us;             // the list schedule's estimate of the persistent launch (fill_sched.h: DagScheduler), microseconds
+    size_t off_launch, off_seg, off_run, bytes;
 };
 
 inline lcgp_fill::PlanParams plan_params(int dtype, int nb, int q, bool with_inverse, const lcgp_sched& sc, int* inverse_done) {
@@ -2502,7 +2513,7 @@ inline lcgp_fill::PlanParams plan_params(int dtype, int nb, int q, bool with_inv
     pp.syrk_small_tiles = sc.syrk_small_tiles; pp.fill_leaf = sc.fill_leaf; pp.fill_step = sc.fill_step;
     pp.leaf_in_wide = sc.leaf_in_wide;
     pp.interleaved = sc.dag == 2;
-    pp.with_trtri = pp.interleaved && with_inverse;
+    pp.with_trtri = pp.interleaved && with_inverse && !(sc.dag_flags & 256);      // (256: the factorisation alone in the persistent launch)
     {
         const int nb2 = nb / 2;
         pp.trtri_all_small = (long long)q * (nb2 * (nb2 + 1) / 2) < sc.trtri_small_tiles ? 1 : 0;
@@ -2545,13 +2556,29 @@ inline size_t make_plan(int dtype, int n, int q, bool with_inverse, const lcgp_s
     (void)hipGetLastError();
     h.num_cu = ncu;
     h.off_launch = (sizeof(PlanHeader) + 255) & ~size_t(255);
+    // the order of the sequence: the launch order itself (dag = 1), or a list schedule of the graph (dag = 2)
+    std::vector<lcgp_fill::DagRun> runs;
+    double sim_us = 0.0;
+    if (dag_ok) {
+        if (sc.dag == 2 && !(sc.dag_flags & 128)) {
+            lcgp_fill::DagScheduler sch;
+            sch.run(dag.segs, 2 * ncu, plan_params(dtype, nb, q, with_inverse, sc, nullptr).ob);
+            if (!sch.failed) { runs.swap(sch.runs); sim_us = sch.makespan_us; }
+        }
+        if (runs.empty())
+            for (size_t i = 0; i < dag.segs.size(); ++i) runs.push_back({(int)i, 0, dag.segs[i].ntasks, dag.segs[i].t0});
+    }
+    h.nruns = (int)runs.size();
+    h.sim_us = sim_us;
     h.off_seg = (h.off_launch + sizeof(lcgp_fill::Launch) * h.nlaunch + 255) & ~size_t(255);
-    h.bytes = (h.off_seg + sizeof(DagSeg) * h.nseg + 255) & ~size_t(255);
+    h.off_run = (h.off_seg + sizeof(DagSeg) * h.nseg + 255) & ~size_t(255);
+    h.bytes = (h.off_run + sizeof(lcgp_fill::DagRun) * h.nruns + 255) & ~size_t(255);
     if (out) {
         memset(out, 0, h.bytes);
         memcpy(out, &h, sizeof(h));
         memcpy((char*)out + h.off_launch, plan.launches.data(), sizeof(lcgp_fill::Launch) * h.nlaunch);
         if (h.nseg) memcpy((char*)out + h.off_seg, dag.segs.data(), sizeof(DagSeg) * h.nseg);
+        if (h.nruns) memcpy((char*)out + h.off_run, runs.data(), sizeof(lcgp_fill::DagRun) * h.nruns);
     }
     return h.bytes;
 }
@@ -2603,6 +2630,8 @@ int do_potrf(hipStream_t st, const Ws& w, const lcgp_sched& sc, bool stats_zeroe
             a.logdet = logdet; a.info = info;
             a.segs = (const DagSeg*)((const char*)plan_dev + h->off_seg);
             a.nseg = h->nseg; a.ntasks = h->ntasks;
+            a.runs = (const lcgp_fill::DagRun*)((const char*)plan_dev + h->off_run);
+            a.nruns = h->nruns;
             a.ctl = ctl;
             a.spin_limit = h->sched.dag_spin_limit > 0 ? (unsigned)h->sched.dag_spin_limit : 2000000u;
             a.flags = h->sched.dag_flags;

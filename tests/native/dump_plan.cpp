@@ -53,6 +53,12 @@ int main(int argc, char** argv) {
             for (int i = 0; i < s.ndeps; ++i) printf("%s%d:%d", i ? "," : "", s.dep[i], s.need[i]);
             printf("\n");
         }
+        // the order of the one task sequence: a list schedule of the graph (DagScheduler); runs of (segment, first task, count)
+        lcgp_fill::DagScheduler sch;
+        sch.run(db.segs, 512, pp.ob);
+        if (sch.failed) { printf("FAILED\n"); return 1; }
+        for (const lcgp_fill::DagRun& r : sch.runs) printf("R seg=%d b0=%d n=%d t0=%d\n", r.seg, r.b0, r.n, r.t0);
+        printf("M makespan_us=%d\n", (int)sch.makespan_us);
     }
     return 0;
 }

@@ -31,6 +31,7 @@ def dump_plan(tmp_path_factory):
         assert 'FAILED' not in out
         launches = []
         segs = []
+        runs = []
         for line in out.splitlines():
             f = line.split()
             d = {}
@@ -41,7 +42,11 @@ def dump_plan(tmp_path_factory):
                     deps = [tuple(int(y) for y in x.split(':')) for x in v.split(',') if x]
                 else:
                     d[k] = int(v)
-            if f[0] == 'L':
+            if f[0] == 'R':
+                runs.append(d)
+            elif f[0] == 'M':
+                continue
+            elif f[0] == 'L':
                 d['jobs'] = []
                 launches.append(d)
             elif f[0] == 'J':
@@ -53,6 +58,7 @@ def dump_plan(tmp_path_factory):
                 d['jobs'] = [dict(type=d['type'], nblk=d['nblk'], t0=d['jt0'], R0=d['R0'], R1=d['R1'], j0=d['j0'], j1=d['j1'],
                                   kb0=d['kb0'], kb1=d['kb1'])] if d['kind'] == 4 else []
                 segs.append(d)
+        run.last_runs = runs
         return (launches, segs) if dag else launches
     return run
 
@@ -512,3 +518,34 @@ def test_interleaved_order_with_the_triangular_inverse(dump_plan, nb, q, ob, kw)
     for i, sg in enumerate(segs):
         if sg['kind'] in (1, 2, 3):
             assert all(segs[d]['kind'] != 5 for d, _ in sg['deps']), (i, sg)
+
+
+def check_runs(segs, runs, q):
+    """the sequence the persistent kernel takes its tasks in: every segment's tasks exactly once, in order, and every run
+    behind ALL runs of everything its segment depends on (so that a task that has been taken only ever waits for tasks
+    before it in the sequence: no deadlock, whatever the number of resident workgroups)"""
+    pos_last = {}
+    nxt = [0] * len(segs)
+    t0 = 0
+    for i, r in enumerate(runs):
+        assert r['t0'] == t0 and r['n'] > 0
+        t0 += r['n']
+        sg = segs[r['seg']]
+        assert r['b0'] == nxt[r['seg']], 'runs of a segment in task order'
+        nxt[r['seg']] += r['n']
+        for d, _ in sg['deps']:
+            assert nxt[d] == segs[d]['ntasks'], 'run %d of segment %d starts before segment %d has been taken whole' % (i, r['seg'], d)
+    assert all(nxt[i] == sg['ntasks'] for i, sg in enumerate(segs))
+    assert t0 == sum(sg['ntasks'] for sg in segs)
+
+
+@pytest.mark.parametrize('nb,q,ob,kw', [(64, 8, 4, {}), (64, 1, 4, {}), (64, 2, 4, {}), (16, 4, 4, {}), (32, 6, 4, {}), (18, 1, 4, {}),
+                                        (10, 3, 4, {}), (2, 1, 4, {}), (24, 2, 8, {}), (12, 1, 2, {}), (14, 2, 6, {}),
+                                        (32, 2, 4, dict(trtri_all_small=1))])
+@pytest.mark.parametrize('mode', ['launch order', 'interleaved', 'interleaved with inverse'])
+def test_scheduled_sequence_is_a_valid_order_of_the_graph(dump_plan, nb, q, ob, kw, mode):
+    extra = dict(interleaved=0) if mode == 'launch order' else dict(interleaved=1, with_trtri=int(mode.endswith('inverse')))
+    if mode == 'launch order':
+        kw = {k: v for k, v in kw.items() if k != 'trtri_all_small'}
+    launches, segs = dump_plan(nb, q, ob, progressive=int(mode == 'launch order' and (ob & (ob - 1)) == 0), dag=1, **extra, **kw)
+    check_runs(segs, dump_plan.last_runs, q)

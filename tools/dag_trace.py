@@ -27,6 +27,7 @@ def main():
     ap.add_argument('--dag', type=int, default=2)
     ap.add_argument('--config', type=int, default=3)
     ap.add_argument('--bucket', type=float, default=100.0)
+    ap.add_argument('--chain', type=int, default=0, help='print the first N tasks of the diagonal-block chain of component 0')
     ap.add_argument('fields', nargs='*')
     a = ap.parse_args()
     x, y, cfg = synth.make_config(a.config)
@@ -64,10 +65,12 @@ def main():
     ints = np.frombuffer(host[:48].tobytes(), dtype=np.int32)
     nseg = int(ints[8])
     sched_ints = C.sizeof(_hip.Sched) // 4
-    off = 48 + 4 * sched_ints
+    off = 48 + 4 * sched_ints + 4
     off = (off + 7) & ~7
-    off_launch, off_seg, nbytes = (int(v) for v in np.frombuffer(host[off:off + 24].tobytes(), dtype=np.uint64))
-    segsz = (nbytes - off_seg) // max(nseg, 1)
+    sim_us = float(np.frombuffer(host[off:off + 8].tobytes(), dtype=np.float64)[0])
+    off += 8
+    off_launch, off_seg, off_run, nbytes = (int(v) for v in np.frombuffer(host[off:off + 32].tobytes(), dtype=np.uint64))
+    print('list-schedule estimate of the launch: %.0f us' % sim_us)
     # sizeof(DagSeg): derive from the table span (padded to 256): use the known layout instead
     import struct
     seg_ints = 6 + 16 + 16 + 7 + 4 + 2 + 4 + 4 + 9     # kind,t0,ntasks,per_comp,k_off,ndeps | dep | need | J.. | c_lo.. | t_first,t_count | r_lo,r_hi,trmm_r0,upd_r0 | job
@@ -106,6 +109,32 @@ def main():
     print('slot-time: wait %.1f %%, body %.1f %%, publish+queue %.1f %%, idle/other %.1f %% of %d slots x %.1f us' % (
         100 * tot[0] / (slots * span), 100 * tot[1] / (slots * span), 100 * tot[2] / (slots * span),
         100 * (1 - sum(tot) / (slots * span)), slots, span))
+    if a.chain:
+        # the chain of component 0: leaf tasks and the special task (task 0 of a step segment that has one)
+        rows = []
+        for i in range(nt):
+            kd = kinds[seg[i]]
+            if kd[0] == 1 or (kd[0] == 2 and kd[4]):
+                rows.append((t_take[i], i))
+        rows.sort()
+        seen = set()
+        prev_pub = None
+        print('chain of component 0: segment kind | taken | waited | body | publish | gap since the previous chain task was published')
+        n = 0
+        for _, i in rows:
+            if seg[i] in seen:
+                continue                       # (first task of the segment in sequence order = component 0)
+            first = min(j for j in range(max(0, i - 16), min(nt, i + 16)) if seg[j] == seg[i])
+            if first != i:
+                continue
+            seen.add(seg[i])
+            gap = (t_ready[i] - prev_pub) if prev_pub is not None else 0.0
+            print('  %-5s taken %9.1f waited %6.1f body %6.1f publish %5.1f   gap %6.1f' % (
+                names[kinds[seg[i]][0]], t_take[i] - t0, t_ready[i] - t_take[i], t_body[i] - t_ready[i], t_pub[i] - t_body[i], gap))
+            prev_pub = t_pub[i]
+            n += 1
+            if n >= a.chain:
+                break
     nbk = int(span / a.bucket) + 1
     comp = np.zeros(nbk)
     wait = np.zeros(nbk)
