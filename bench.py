@@ -315,7 +315,7 @@ def main():
                        ranks=ranks)
 
     # ---- wall-clock fit() of the same configuration (the metric names it; lcgp.py:537-540), all ranks in lock-step ----
-    if not args.no_fit and dtype == 'float64':       # (the float32 configuration's fit is a minute of evaluations: tools/fit_wallclock.py)
+    if not args.no_fit:
         mf = LCGP(y=y, x=x, q=cfg['q'], submethod=cfg['submethod'], dtype=dtype, device='cuda:%d' % dev_index)
         mf._get_engine()
         barrier()
@@ -332,6 +332,10 @@ def main():
         out['fit'] = dict(fit_wallclock_s=t_fit, iterations=int(res.nit), evaluations=int(res.nfev), final_loss=float(res.fun),
                           converged=bool(res.success), message=str(res.message),
                           predict_2000_wallclock_s=t_pred,
+                          restarts=len(getattr(res, 'restarts', [])) - 1,
+                          float32_fallbacks=(int(res.float32_fallbacks) if dtype == 'float32' else None),
+                          float64_only=(bool(res.float64_only) if dtype == 'float32' else None),
+                          ms_per_evaluation=1e3 * t_fit / max(int(res.nfev), 1),
                           note='LCGP(...).fit() from the initial parameters (scipy L-BFGS-B, defaults) on this run\'s ranks; '
                                'the reference algorithm needs one cpu_baseline evaluation per L-BFGS-B evaluation')
         log('fit: %.3f s, %d iterations, %d evaluations, final loss %.6g' % (t_fit, res.nit, res.nfev, res.fun))
@@ -398,6 +402,17 @@ def main():
         out['parity'] = dict(nll_rel_err=e_v, grad_rel_err=e_g, n_sample=ns, nll_tol=tol_v, grad_tol=tol_g,
                              passed=bool(e_v <= tol_v and e_g <= tol_g))
         del eng
+    if rank == 0 and args.q is not None and world == 1:
+        # `--q Q` runs ONE rank's share of the configuration on this one GPU: with component k on rank k mod G that is the
+        # load of every rank of a G = q_config / Q GPU job, so the line also says what it projects to (an all-reduce of
+        # ~1 KB per evaluation is the only thing a real job adds).  A PROJECTION, printed so that the first measured
+        # SCALE record can be read against it -- never a measured multi-GPU number.
+        q_full = int(synth.CONFIGS[args.config]['q'])
+        if q_full % args.q == 0:
+            g = q_full // args.q
+            out['projected_from_q_local'] = dict(q_local=args.q, n_gpus=g, ms_per_step=out['ms_per_step'],
+                                                 evals_per_s=1e3 / out['ms_per_step'],
+                                                 note='projection from a one-GPU run of one rank\'s share; not a measured %d-GPU number' % g)
     if rank == 0:
         print(json.dumps(out))
     if world > 1:

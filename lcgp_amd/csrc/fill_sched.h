@@ -22,6 +22,7 @@
 #define LCGP_FILL_SCHED_H
 
 #include <stddef.h>
+#include <string.h>
 #include <utility>
 #include <vector>
 
@@ -292,6 +293,8 @@ enum LaunchKind {
 };
 
 struct Launch {
+    // every byte zero, padding and the executor-owned pointers of `fs` included: a plan is compared and hashed as bytes
+    Launch() { memset((void*)this, 0, sizeof(*this)); }
     int kind = 0;
     int J = 0, pe = 0, c = 0;
     int diag_end = 0, has_special = 0, n_trmm = 0, n_upd = 0;       // L_STEP

@@ -79,18 +79,36 @@ def all_reduce_sum(vec, group=None, device=None):
 
 
 def gather_rows(local_rows, q: int, group=None, device=None):
-    """Assemble a (q, m) array from per-rank rows of the components `local_components(q, rank, world)`."""
+    """Assemble a (q, m) array from per-rank rows of the components `local_components(q, rank, world)`: ONE all_gather of
+    the local rows (every rank sends ceil(q / world) rows, padded; nothing is summed and no rank ships zeros for the
+    components it does not hold -- round 3 summed q x m zero-padded blocks with an all-reduce, 1 GB for the (q, n, n)
+    cache views at the headline size)."""
     rank, world = rank_world(group)
     local_rows = np.asarray(local_rows, np.float64)
     m = local_rows.shape[1] if local_rows.ndim == 2 else 0
     full = np.zeros((q, m), np.float64)
     ks = local_components(q, rank, world)
-    if len(ks):
-        full[ks] = local_rows
     if not use_collectives(group):
+        if len(ks):
+            full[ks] = local_rows
         return full
-    # disjoint rows: a sum is a gather
-    return all_reduce_sum(full.reshape(-1), group, device).reshape(q, m)
+    import torch
+    dist = _dist()
+    per = (q + world - 1) // world                     # rows a rank holds at most (component k -> rank k mod world)
+    mine = np.zeros((per, m), np.float64)
+    if len(ks):
+        mine[:len(ks)] = local_rows
+    t = torch.as_tensor(mine)
+    if backend_is_nccl(group):
+        t = t.to(device if device is not None else torch.device("cuda", torch.cuda.current_device()))
+    out = torch.empty((world * per, m), dtype=torch.float64, device=t.device)
+    dist.all_gather_into_tensor(out, t.contiguous(), group=group)
+    got = out.cpu().numpy().reshape(world, per, m)
+    for r in range(world):
+        rk = local_components(q, r, world)
+        if len(rk):
+            full[rk] = got[r, :len(rk)]
+    return full
 
 
 def broadcast_array(arr, src=0, group=None, device=None):

@@ -69,10 +69,21 @@ class LCGP:
         self.rep_standardize_ybar = rep_standardize_ybar
         self.parameter_clamp_flag = parameter_clamp_flag
         self._device = device
-        self._dtype = dtype
+        # arithmetic of the device path: the reference is float64 only (lcgp.py:16); aliases are normalised ONCE here, every
+        # later test compares with the normalised name
+        try:
+            self._dtype = {'float64': 'float64', 'f64': 'float64', 'float32': 'float32', 'f32': 'float32'}[str(dtype)]
+        except KeyError:
+            raise ValueError("dtype must be 'float64' or 'float32' (aliases 'f64', 'f32'), got %r" % (dtype,))
         self._engine64 = None            # float32 models: float64 engine for points where the float32 factorisation fails
         self.float32_fallback = True
         self.float32_fallbacks = 0
+        # float32 models: after this many CONSECUTIVE evaluations that had to be repeated in float64 the model stops trying
+        # float32 (every such point pays a wasted float32 evaluation first): the run continues on the float64 engine alone and
+        # the float32 workspace is released.  info is all-reduced, so every rank counts the same and switches together.
+        self.float32_switch_after = 3
+        self._f32_consecutive = 0
+        self._float64_only = False
         self._last_eval_float64 = False
         self._aux_engine = None          # the engine whose workspace holds the factorisation of _u_last
         self._group = process_group
@@ -386,6 +397,8 @@ class LCGP:
                              comp_ids=self._local_ks, q_total=self.q)
 
     def _get_engine(self):
+        if self._float64_only:           # a float32 model that has given up on float32 (float32_switch_after)
+            return self._engine64
         if self._engine is None:
             self._engine = self._make_engine()
             self._path_consts()
@@ -461,23 +474,33 @@ class LCGP:
                                    'differ: guard sum %.17g != %d x %.17g); every rank stops here' % (v[-1], world, guard))
             return v[:-1]
 
+        if self._float64_only:
+            eng = self._engine64
         vec = reduced(eng)
         if vec[1] < 0:
             # not a property of the matrix: a wait inside the persistent factorisation launch expired (lcgp_sched.dag,
             # include/lcgp_hip.h) and the launch drained with info = -1 on every component
             raise RuntimeError('lcgp_amd: the persistent factorisation launch gave up a wait (info=%g); '
                                'nothing was computed at these parameters' % vec[1])
-        if (vec[1] != 0 or not np.isfinite(vec[0])) and self._dtype == 'float32' and self.float32_fallback:
+        if self._float64_only:
+            self._last_eval_float64 = True
+        elif (vec[1] != 0 or not np.isfinite(vec[0])) and self._dtype == 'float32' and self.float32_fallback:
             # The float32 factorisation broke down (I + D_k C_k has a condition number beyond single precision somewhere
             # along a line search; the reference is float64 only).  The point is evaluated again in float64 -- on every
             # rank: info was all-reduced -- so the optimiser sees the objective there instead of an artificial value.
             if self._engine64 is None and eng is not None:
                 self._engine64 = self._make_engine('float64')
             self.float32_fallbacks += 1
+            self._f32_consecutive += 1
             vec = reduced(self._engine64)
             self._last_eval_float64 = True
+            if self.float32_switch_after and self._f32_consecutive >= self.float32_switch_after:
+                # float32 is not carrying this model: stay on the float64 engine, give the float32 workspace back
+                self._float64_only = True
+                self._engine = None
         else:
             self._last_eval_float64 = False
+            self._f32_consecutive = 0
         if vec[1] != 0 or not np.isfinite(vec[0]):
             raise np.linalg.LinAlgError(
                 'I + D_k C_k is not numerically positive definite at the current parameters (info=%g)' % vec[1])
@@ -518,6 +541,11 @@ class LCGP:
             raise ValueError("Invalid submethod. Choices are 'full' or 'rep'.")
         u0 = self._get_flat()
         last = []
+        if self._dtype == 'float32' and self.float32_fallback and not self._float64_only and self._engine64 is None:
+            # the float64 engine behind the fallback is created BEFORE the optimiser starts: if its workspace does not fit,
+            # that surfaces here, on every rank, and not in the middle of a run that has already made progress
+            self._get_engine()
+            self._engine64 = self._make_engine('float64')
 
         def fun(u):
             try:
@@ -530,14 +558,23 @@ class LCGP:
             return val, g
 
         res = sopt.minimize(fun, u0, jac=True, method='L-BFGS-B')
-        if self._dtype == 'float32':
+        runs = [dict(nit=int(res.nit), nfev=int(res.nfev), fun=float(res.fun), success=bool(res.success), message=str(res.message))]
+        if self._dtype == 'float32' and not self._float64_only:
             # The float32 objective carries rounding noise of ~3e-7 relative, far above L-BFGS-B's default relative-reduction
             # test (2.2e-9): a run ends when one line search returns a step inside the noise.  Restarting from the point it
             # stopped at (fresh curvature memory) until a whole run gains less than 1e-6 relative carries on to where the
             # float64 run ends (tests/test_gpu_configs.py: final losses within 1e-3 relative on the configs[3] prefix).
+            # `opt_result.restarts` keeps every run (iterations, evaluations, value, message); `nit` / `nfev` of the result are the
+            # TOTALS over all runs, everything else describes the accepted (best) run.  The restarts stop after 30 runs, after
+            # 15000 evaluations in all (SciPy's own default budget for one run), or when the model leaves float32.
             total_nit, total_nfev = res.nit, res.nfev
             for _ in range(30):
+                if total_nfev >= 15000 or self._float64_only:
+                    break
+                last[:] = [res.fun]
                 nxt = sopt.minimize(fun, res.x, jac=True, method='L-BFGS-B')
+                runs.append(dict(nit=int(nxt.nit), nfev=int(nxt.nfev), fun=float(nxt.fun), success=bool(nxt.success),
+                                 message=str(nxt.message)))
                 total_nit += nxt.nit
                 total_nfev += nxt.nfev
                 gained = res.fun - nxt.fun
@@ -546,6 +583,9 @@ class LCGP:
                 if not gained > 1e-6 * abs(res.fun):
                     break
             res.nit, res.nfev = total_nit, total_nfev
+        res.restarts = runs
+        res.float32_fallbacks = int(self.float32_fallbacks)
+        res.float64_only = bool(self._float64_only)
         self._set_flat(res.x)
         self.opt_result = res
         return
@@ -687,11 +727,13 @@ class LCGP:
 
     # ---- cache views the reference keeps as attributes (materialised from the device only when read) ----
     def _fetch_all(self, fn, width):
-        eng = self._aux_engine if self._engine is not None else None
+        """(q, width) from per-component rows: every rank computes `fn` for the components IT holds (also any host-side
+        work hidden in `fn`, e.g. the eigendecomposition behind `Ths`), then one all_gather assembles the rows."""
+        eng = self._aux_engine
         rows = np.zeros((len(self._local_ks), width), F64)
         if eng is not None:
             for i in range(len(self._local_ks)):
-                rows[i] = fn(eng, i).reshape(-1)
+                rows[i] = np.asarray(fn(eng, i), F64).reshape(-1)
         return _dist.gather_rows(rows, int(self.q), self._group, None if eng is None else eng.device)
 
     def _cache_get(self, name):
@@ -724,12 +766,13 @@ class LCGP:
             # eigendecomposition of A^-1 per component on the host when -- and only when -- it is read.
             if self.submethod != 'full':
                 return None
-            ainv = self._fetch_all(lambda e, i: e.fetch_matrix(2, i), n * n).reshape(int(self.q), n, n)
-            out = np.empty_like(ainv)
-            for k in range(int(self.q)):
-                lam, vec = np.linalg.eigh(0.5 * (ainv[k] + ainv[k].T))
-                out[k] = (vec * np.sqrt(D[k] * np.maximum(lam, 0.0))[None, :]) @ vec.T
-            return _t(out)
+            # Each rank takes the square root of the components it OWNS (one eigendecomposition per owned component, not q
+            # on every rank) and the finished rows are gathered.
+            def sqrt_owned(e, i):
+                ainv = e.fetch_matrix(2, i)
+                lam, vec = np.linalg.eigh(0.5 * (ainv + ainv.T))
+                return (vec * np.sqrt(D[self._local_ks[i]] * np.maximum(lam, 0.0))[None, :]) @ vec.T
+            return _t(self._fetch_all(sqrt_owned, n * n).reshape(int(self.q), n, n))
         raise AttributeError(name)
 
     def _cache_set(self, name, value):

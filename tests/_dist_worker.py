@@ -47,6 +47,32 @@ def main():
         want = o.predict(x0)
         for a, b in zip(got, want):
             np.testing.assert_allclose(a.numpy(), b, rtol=1e-7, atol=1e-9)
+        # the cache views (lcgp.py:709-715 / 783-788) with the components spread over the ranks (3 on 2 ranks: 2 + 1; 4 on 2:
+        # 2 + 2): ONE all_gather of the rows each rank owns -- for Ths every rank takes the matrix square root of its OWN
+        # components only -- and every rank ends with the identical, complete (q, ...) array
+        views = dict(CinvMs=m.CinvMs.numpy(), mks=m.mks.numpy())
+        if mode == 'full':
+            views['Ths'] = m.Ths.numpy()
+            assert views['Ths'].shape == (q, int(m.n), int(m.n))
+            # Th_k Th_k = D_k A_k^-1 (symmetric square root): check against the oracle's A_k^-1 through CinvM = A^-1 B
+            aux = o._aux_full()
+            np.testing.assert_allclose(views['Ths'], np.asarray(aux['Ths']), rtol=1e-6, atol=1e-9)
+        else:
+            views['Tks'] = m.Tks.numpy()
+            assert views['Tks'].shape == (q, int(m.n), int(m.n))
+            aux = o._aux_rep()
+            # (the oracle follows the reference literally here: explicit inverses of C_k and of C_k^-1 + D_k R, lcgp.py:783-788,
+            # which lose digits at the fitted nugget of 1e-7; the path under test forms D R^1/2 A^-1 R^1/2 from the well
+            # conditioned A -- what this job checks is the GATHER: complete, finite, identical on both ranks)
+            want = np.asarray(aux['Tks'])
+            np.testing.assert_allclose(views['Tks'], want, rtol=2e-2, atol=2e-3 * np.max(np.abs(want)))
+            np.testing.assert_allclose(views['mks'], np.asarray(aux['mks']), rtol=1e-6, atol=1e-9)
+        np.testing.assert_allclose(views['CinvMs'], np.asarray(aux['CinvMs']), rtol=1e-6, atol=1e-9)
+        for name, v in views.items():
+            assert np.all(np.isfinite(v)), name
+            both = [None, None]
+            dist.all_gather_object(both, v.tobytes())
+            assert both[0] == both[1], name
     # lock-step guard: one rank evaluates a parameter vector that differs by ONE ULP in one entry -- every rank must
     # raise at that evaluation (after the same collective), not hang in a later one; both can carry on afterwards
     x, y = synth.make_full(24, 30, 2, 3, 2)

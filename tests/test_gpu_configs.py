@@ -183,6 +183,14 @@ def test_cfg4_float32_quadratic_form_without_cancellation_and_fit():
     print('cfg4 prefix fit: float64 %.6f (%d evaluations), float32 %.6f re-evaluated in float64 (%d evaluations, %d of them '
           'fell back to float64)' % (f64, m64.opt_result.nfev, f32_in_64, m32.opt_result.nfev, m32.float32_fallbacks))
     assert abs(f32_in_64 - f64) <= 1e-3 * abs(f64)
+    # the policy of round 4: after 3 consecutive evaluations that had to be repeated in float64 the run stays in float64
+    # (no wasted float32 attempt per point any more); what happened is on the result object
+    r = m32.opt_result
+    assert r.float32_fallbacks == m32.float32_fallbacks and len(r.restarts) >= 1
+    assert sum(t['nfev'] for t in r.restarts) == r.nfev and sum(t['nit'] for t in r.restarts) == r.nit
+    if r.float64_only:
+        assert m32._engine is None and m32._get_engine() is m32._engine64
+        assert m32.float32_fallbacks <= r.nfev
     # predictions after such a fit come from whichever engine holds the factorisation of the fitted parameters
     x0 = np.random.default_rng(3).uniform(0, 1, (20, x.shape[1]))
     m64._set_flat(m32._get_flat())
