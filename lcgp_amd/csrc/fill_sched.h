@@ -16,8 +16,9 @@
 //     DUPD         V[<=P,<=P] (+)= W[P,<=P]^T W[P,<=P]              (V ends as A^-1; rows of panel P are first written here)
 //
 // This header is plain C++ (no HIP): the descriptors are shared with the device code, and the scheduler is exercised on
-// the CPU by tests/native/test_fill_sched.cpp, which replays a schedule symbolically and checks every read-after-write
-// and write-after-write constraint launch by launch.
+// the CPU by tests/test_fill_sched.py (through tests/native/dump_plan.cpp, which prints a plan as text): the plan is
+// replayed on numpy matrices with the semantics of the kernels and every read-after-write and write-after-write constraint
+// is checked launch by launch -- and, for the persistent form, segment by segment against the derived dependency lists.
 #ifndef LCGP_FILL_SCHED_H
 #define LCGP_FILL_SCHED_H
 
@@ -262,7 +263,7 @@ class FillQueue {
 // ---------------------------------------------------------------------------------------------------
 // The launch plan of one factorisation (+ progressive inverse): computed on the host before anything is enqueued, from
 // the block count, the number of components and the schedule parameters alone.  lcgp_hip.hip executes it launch by
-// launch; tests/native/test_fill_sched.cpp replays it symbolically on the CPU.
+// launch; tests/test_fill_sched.py replays it on the CPU (tests/native/dump_plan.cpp prints it).
 // ---------------------------------------------------------------------------------------------------
 struct PlanParams {
     int nb;                  // 64-blocks per side (even)

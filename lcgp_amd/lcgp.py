@@ -559,17 +559,18 @@ class LCGP:
 
         res = sopt.minimize(fun, u0, jac=True, method='L-BFGS-B')
         runs = [dict(nit=int(res.nit), nfev=int(res.nfev), fun=float(res.fun), success=bool(res.success), message=str(res.message))]
-        if self._dtype == 'float32' and not self._float64_only:
+        if self._dtype == 'float32':
             # The float32 objective carries rounding noise of ~3e-7 relative, far above L-BFGS-B's default relative-reduction
             # test (2.2e-9): a run ends when one line search returns a step inside the noise.  Restarting from the point it
             # stopped at (fresh curvature memory) until a whole run gains less than 1e-6 relative carries on to where the
             # float64 run ends (tests/test_gpu_configs.py: final losses within 1e-3 relative on the configs[3] prefix).
             # `opt_result.restarts` keeps every run (iterations, evaluations, value, message); `nit` / `nfev` of the result are the
-            # TOTALS over all runs, everything else describes the accepted (best) run.  The restarts stop after 30 runs, after
-            # 15000 evaluations in all (SciPy's own default budget for one run), or when the model leaves float32.
+            # TOTALS over all runs, everything else describes the accepted (best) run.  The restarts stop after 30 runs or after
+            # 15000 evaluations in all (SciPy's own default budget for one run).  A model that has switched to float64 on the
+            # way (float32_switch_after) is restarted by the same rule: its curvature memory was built on float32 values.
             total_nit, total_nfev = res.nit, res.nfev
             for _ in range(30):
-                if total_nfev >= 15000 or self._float64_only:
+                if total_nfev >= 15000:
                     break
                 last[:] = [res.fun]
                 nxt = sopt.minimize(fun, res.x, jac=True, method='L-BFGS-B')

@@ -10,6 +10,11 @@ so these vectors come from the oracle, which is pinned by the reference's stored
                                                   # (n=4096 q=8 fp64; rep n_unique=2048 x 5; the 4096-point prefix of
                                                   #  the n=16384 fp32 configuration in fp64) -- about 5 minutes of CPU
 
+    python tests/golden/make_golden.py --huge     # ONE component of configs[3] at its FULL size n = 16384 in float64 (the size
+                                                  # the other fixtures only reach through properties): NLL_k and its 12 kernel
+                                                  # gradient entries at one parameter point -> lcgp_golden_huge.npz
+                                                  # (about 20 GB of host memory, a few CPU-minutes)
+
 Inputs are regenerated from seeds (lcgp_amd/synth.py, tests/kat_data.py); only expected outputs are
 stored: NLL, gradient w.r.t. the unconstrained vector, per-component pieces, and a few predictions.
 """
@@ -94,7 +99,36 @@ def generate(cases, fname):
     print('wrote', os.path.join(HERE, fname))
 
 
+def generate_huge():
+    """configs[3] (n = 16384, d = 10, p = 32, q = 8) at full size, component 0 only, parameter point theta_1: the Cholesky form
+    of lcgp.py:635-666 with the closed-form gradient (oracle/cpu_baseline.py::chol_form_component, the same restatement the
+    bench's CPU leg times, pinned by tests/test_oracle_identities.py against the literal eigh form and autodiff).  Stored:
+    the theta row of the component (so that the GPU test feeds the identical numbers), half log-determinant, quadratic
+    form, NLL_k, d/d(ell_1..10, scale, nug), and Y (b - z)."""
+    from oracle import cpu_baseline
+    x, y, cfg = synth.make_config(4)
+    m = orc.OracleLCGP(y=y, x=x, q=cfg['q'], submethod='full')
+    u = synth.param_points(4, m.get_unconstrained())[1]
+    m.set_unconstrained(u)
+    lLmb, lLmb0, ls2b, lnug = m.get_param()
+    k = 0
+    dt, pc = cpu_baseline.chol_form_component(m.x, m.y, m.phi[:, k], float(m.diag_D[k]), lLmb[k], float(lLmb0[k]),
+                                              float(lnug[k]), ls2b)
+    theta = np.concatenate([lLmb[k], [lLmb0[k], lnug[k], m.diag_D[k]], m.phi[:, k] / np.exp(0.5 * ls2b)])
+    out = {'cfg4_full_k0/u': u, 'cfg4_full_k0/theta': theta, 'cfg4_full_k0/half_logdet': pc['half_logdet'],
+           'cfg4_full_k0/quad': pc['quad'], 'cfg4_full_k0/nll_k': pc['value'],
+           'cfg4_full_k0/g_kernel': np.concatenate([pc['g_ell'], [pc['g_scale'], pc['g_nug']]]),
+           'cfg4_full_k0/gsig': pc['gsig'], 'cfg4_full_k0/diag_D': np.asarray(m.diag_D)}
+    print('cfg4 full size, component 0: %.1f s on the host; NLL_k %.10g, half logdet %.10g, quad %.10g' % (
+        dt, pc['value'], pc['half_logdet'], pc['quad']), flush=True)
+    np.savez_compressed(os.path.join(HERE, 'lcgp_golden_huge.npz'), **out)
+    print('wrote', os.path.join(HERE, 'lcgp_golden_huge.npz'))
+
+
 def main():
+    if '--huge' in sys.argv[1:]:
+        generate_huge()
+        return
     if '--ragged' in sys.argv[1:]:
         generate(ragged_case_models(), 'lcgp_golden_ragged.npz')
     elif '--large' in sys.argv[1:]:
