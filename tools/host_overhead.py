@@ -17,7 +17,8 @@ import torch  # noqa: E402
 from lcgp_amd import LCGP, synth  # noqa: E402
 
 cfgid = int(sys.argv[1]) if len(sys.argv) > 1 else 3
-x, y, cfg = synth.make_config(cfgid)
+over = {'q': int(sys.argv[2])} if len(sys.argv) > 2 else {}          # e.g. `3 1`: one rank's share of the headline configuration
+x, y, cfg = synth.make_config(cfgid, **over)
 m = LCGP(y=y, x=x, q=cfg['q'], submethod=cfg['submethod'], dtype='float64' if cfg['dtype'] == 'f64' else 'float32')
 pts = synth.param_points(cfgid, m._get_flat())
 for u in pts:
@@ -26,22 +27,31 @@ eng = m._engine
 st = torch.cuda.current_stream(eng.device)
 sig = np.exp(0.5 * np.repeat(m.lsigma2s.numpy(), np.asarray(m.diag_error_structure, int))) / m._std
 theta = m._theta_rows(sig)
-wall, gpu, enq = [], [], []
-for rep in range(12):
-    u = pts[rep % len(pts)]
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    m.loss_and_grad(u)
-    wall.append(1e3 * (time.perf_counter() - t0))
-    torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    t0 = time.perf_counter()
-    e0.record(st)
-    eng.evaluate_partial(theta)
-    e1.record(st)
-    enq.append(1e3 * (time.perf_counter() - t0))
-    torch.cuda.synchronize()
-    gpu.append(e0.elapsed_time(e1))
-w, g, e = np.median(wall), np.median(gpu), np.median(enq)
-print('cfg %d (n=%d q=%d %s): loss_and_grad %.3f ms wall, GPU %.3f ms, host overhead %.3f ms per evaluation '
-      '(enqueue of one evaluation returns after %.3f ms)' % (cfgid, int(m.n), int(m.q), cfg['dtype'], w, g, w - g, e))
+def measure():
+    wall, gpu, enq = [], [], []
+    for rep in range(12):
+        u = pts[rep % len(pts)]
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        m.loss_and_grad(u)
+        wall.append(1e3 * (time.perf_counter() - t0))
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        e0.record(st)
+        eng.evaluate_partial(theta)
+        e1.record(st)
+        enq.append(1e3 * (time.perf_counter() - t0))
+        torch.cuda.synchronize()
+        gpu.append(e0.elapsed_time(e1))
+    return np.median(wall), np.median(gpu), np.median(enq)
+
+
+# the launch plan built ONCE by the caller (lcgp_plan_build, the engine's default) against planning inside every call
+for label, use_plan in (('caller-owned plan', True), ('plan per call (plan_host = NULL)', False)):
+    eng.use_plan = use_plan
+    m.loss_and_grad(pts[0])
+    w, g, e = measure()
+    print('cfg %d (n=%d q=%d %s), %s: loss_and_grad %.3f ms wall, GPU %.3f ms, host overhead %.3f ms per evaluation '
+          '(enqueue of one evaluation returns after %.3f ms)' % (cfgid, int(m.n), int(m.q), cfg['dtype'], label, w, g, w - g, e))
+eng.use_plan = True
