@@ -2,7 +2,7 @@
     python tools/dag_diff.py n q reps [dag] [flags]"""
 import sys
 import numpy as np
-sys.path.insert(0, '.')
+sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
 from lcgp_amd import LCGP, synth, _hip  # noqa: E402
 
 n, q, reps = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])

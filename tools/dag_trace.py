@@ -15,7 +15,7 @@ import sys
 import numpy as np
 import torch
 
-sys.path.insert(0, '.')
+sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
 from lcgp_amd import LCGP, synth, _hip  # noqa: E402
 
 CAP = 1 << 18
