@@ -96,6 +96,10 @@ typedef struct lcgp_sched {
                                4 = system-scope instead of agent-scope acquire,
                                8 = plain result stores and a release fence instead of write-through stores,
                                16 = the next task is taken after the publication instead of before the drain */
+    int fill_wide;          /* launch-by-launch plans: 1 = the filler tiles of the trailing update's far columns and of the
+                               rank-256 updates of the progressive inverse are 128x128 (the shape of the wide tile kernel, on
+                               the four waves of a chain launch) instead of 128x64; fill_leaf / fill_step keep counting
+                               128x64 tiles, such a tile takes two of them (0 with `dag`) */
 } lcgp_sched;
 int lcgp_sched_default(lcgp_sched* sched /*host out*/);
 

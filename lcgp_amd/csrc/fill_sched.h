@@ -46,6 +46,9 @@ struct FillJob {
     int t0;              // first tile
     int R0, R1, j0, j1;
     int kb0, kb1;
+    int wide;            // SYRK / CUPD: 1 = 128 x 128 output tiles -- the columns go in PAIRS (j, j + 1), j even (j0, j1, kb0
+                         // even), same enumeration over the pairs; such a tile is twice the work of a 128 x 64 one at half the
+                         // operand traffic per flop and runs at the rate of the 128-tile kernel
 };
 
 struct FillSet {
@@ -62,13 +65,18 @@ inline long syrk_tiles(int R1, int j0, int j1) {
     for (int j = j0; j < j1; ++j) n += R1 - (j >> 1);
     return n;
 }
+inline long syrk_tiles_wide(int R1, int j0, int j1) {             // column pairs (j0, j1 even)
+    long n = 0;
+    for (int j = j0; j < j1; j += 2) n += R1 - (j >> 1);
+    return n;
+}
 inline long dupd_tiles(int R1) { return (long)R1 * (R1 + 1); }     // rows [0, R1)
 
 // ---------------------------------------------------------------------------------------------------
 // scheduler
 // ---------------------------------------------------------------------------------------------------
 struct QJob {
-    FillJob j;               // type and ranges (nblk / t0 are filled per launch)
+    FillJob j = {};          // type and ranges (nblk / t0 are filled per launch)
     long total = 0;          // tiles
     long next = 0;           // tiles handed out so far
     long avail = 0;          // tiles completed in EARLIER launches (what a dependent job may rely on)
@@ -132,6 +140,8 @@ class FillQueue {
     int take(long cap_blocks, bool allow_big, int urgent_row, FillSet& fs, bool with_dupd = true) {
         fs.njobs = 0;
         fs.nblk = 0;
+        // (the capacity counts 128 x 64 tiles: a wide tile takes two units)
+        auto cost = [&](const QJob& jb) { return (long)q * (jb.j.wide ? 2 : 1); };
         auto emit = [&](QJob& jb, long n) {
             if (n <= 0 || fs.njobs >= NJ) return;
             FillJob& o = fs.job[fs.njobs++];
@@ -140,14 +150,14 @@ class FillQueue {
             o.nblk = (int)(n * q);
             jb.next += n;
             fs.nblk += o.nblk;
-            cap_blocks -= n * q;
+            cap_blocks -= n * cost(jb);
         };
-        auto room = [&]() { return cap_blocks / q; };
+        auto room = [&](const QJob& jb) { return cap_blocks / cost(jb); };
         for (QJob& jb : jobs) {                                   // 1, 2: block inverse and BROW
             if (jb.complete() || (jb.j.type != FILL_TRI_T && jb.j.type != FILL_TRI_W && jb.j.type != FILL_BROW)) continue;
             if (!allow_big && !jb.small) continue;
             long n = limit(jb) - jb.next;
-            if (n > room()) n = room();
+            if (n > room(jb)) n = room(jb);
             emit(jb, n);
         }
         if (!allow_big) return fs.nblk;
@@ -161,7 +171,7 @@ class FillQueue {
                     const long r = cupd_row(jb);
                     if (r < brow) { brow = r; best = i; }
                 }
-                if (best < 0 || room() <= 0 || fs.njobs >= NJ) break;
+                if (best < 0 || cap_blocks < q || fs.njobs >= NJ) break;
                 QJob& jb = jobs[best];
                 // up to the end of the row block group the job is in (whole rows of the next two row blocks)
                 long row_stop = (brow / 2 + 1) * 2;
@@ -169,14 +179,14 @@ class FillQueue {
                 long n = (row_stop - jb.j.R0) * jb.ncols - jb.next;
                 const long lim = limit(jb) - jb.next;
                 if (n > lim) n = lim;
-                if (n > room()) n = room();
+                if (n > room(jb)) n = room(jb);
                 // the same job may be picked again in this launch: merge with its previous descriptor
                 if (fs.njobs > 0 && fs.job[fs.njobs - 1].type == FILL_CUPD && fs.job[fs.njobs - 1].kb0 == jb.j.kb0 &&
                     fs.job[fs.njobs - 1].t0 + fs.job[fs.njobs - 1].nblk / q == jb.next) {
                     fs.job[fs.njobs - 1].nblk += (int)(n * q);
                     jb.next += n;
                     fs.nblk += (int)(n * q);
-                    cap_blocks -= n * q;
+                    cap_blocks -= n * cost(jb);
                 } else {
                     emit(jb, n);
                 }
@@ -187,7 +197,7 @@ class FillQueue {
         if (syrk_job >= 0 && !jobs[syrk_job].complete()) {        // 4
             QJob& jb = jobs[syrk_job];
             long n = limit(jb) - jb.next;
-            if (n > room()) n = room();
+            if (n > room(jb)) n = room(jb);
             emit(jb, n);
         }
         cupd_pass(1L << 40);                                      // 5
@@ -195,7 +205,7 @@ class FillQueue {
         for (QJob& jb : jobs) {                                   // 6
             if (jb.j.type != FILL_DUPD || jb.complete()) continue;
             long n = limit(jb) - jb.next;
-            if (n > room()) n = room();
+            if (n > room(jb)) n = room(jb);
             emit(jb, n);
         }
         return fs.nblk;
@@ -281,6 +291,8 @@ struct PlanParams {
     int trtri_all_small = 0;  // ... every level on 64 x 64 tiles (small problems); else only the first
     int tri_fill_from = 256;  // ... they start to ride when a chain step's share of the far update drops below this many blocks
     bool psolve = true;       // ... and the rows below the chain rows are solved per panel with the panel's 256 x 256 inverse
+    bool fill_wide = false;   // launch-by-launch plan: the far columns of the trailing update and the rank-(64 ob) updates of the
+                              // progressive inverse ride as 128 x 128 tiles (FillJob::wide; needs an even ob)
 };
 
 enum LaunchKind {
@@ -581,6 +593,8 @@ class Planner {
     int last_dupd = -1, last_cupd = -1;
     int kb_end = 0;               // end of the last panel whose inverse jobs are queued
 
+    bool wide_ok() const { return pp.fill_wide && (pp.ob & 1) == 0 && (pp.nb & 1) == 0; }
+
     // the far columns [cf, nb) of the trailing update of panel [J, pe) become the filler job with a deadline at the
     // end of the next panel's chain
     void queue_far_update(int J, int pe, int cf) {
@@ -589,7 +603,8 @@ class Planner {
         QJob jb;
         jb.j.type = FILL_SYRK;
         jb.j.R0 = 0; jb.j.R1 = pp.nb / 2; jb.j.j0 = cf; jb.j.j1 = pp.nb; jb.j.kb0 = J; jb.j.kb1 = pe;
-        jb.total = syrk_tiles(pp.nb / 2, cf, pp.nb);
+        jb.j.wide = wide_ok() && (cf & 1) == 0 ? 1 : 0;
+        jb.total = jb.j.wide ? syrk_tiles_wide(pp.nb / 2, cf, pp.nb) : syrk_tiles(pp.nb / 2, cf, pp.nb);
         jb.ready_launch = fq.launch;
         fq.syrk_job = fq.add(jb);
     }
@@ -634,8 +649,9 @@ class Planner {
             QJob jb;
             jb.j.type = FILL_CUPD;
             jb.j.R0 = pe / 2; jb.j.R1 = nb / 2; jb.j.j0 = 0; jb.j.j1 = pe; jb.j.kb0 = J; jb.j.kb1 = pe;
-            jb.ncols = pe;
-            jb.total = (long)(jb.j.R1 - jb.j.R0) * pe;
+            jb.j.wide = wide_ok() && (pe & 1) == 0 && (J & 1) == 0 ? 1 : 0;
+            jb.ncols = jb.j.wide ? pe / 2 : pe;
+            jb.total = (long)(jb.j.R1 - jb.j.R0) * jb.ncols;
             jb.ready_launch = now + (last_step ? 1 : 0);   // the panel's last block column of L is final after that launch
             jb.dep[0] = w_done;
             jb.wave = last_cupd;

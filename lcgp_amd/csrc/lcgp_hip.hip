@@ -22,7 +22,7 @@
 #include "../../include/lcgp_hip.h"
 #include "fill_sched.h"
 
-#define LCGP_VERSION 300
+#define LCGP_VERSION 310
 
 namespace {
 
@@ -678,7 +678,7 @@ __global__ __launch_bounds__(256, 2) void leaf_kernel(T* __restrict__ M, T* __re
 //   MK : element (m, k) at P[m * ld + k]      KM : element (m, k) at P[k * ld + m]
 // and staged in LDS as [k][m] (KT = 16 k rows per stage, double buffered through registers).
 // ---------------------------------------------------------------------------------------------------
-enum GemmOp { OP_SYRK = 1, OP_TRTRI_T = 2, OP_TRTRI_W = 3, OP_LAUUM = 4, OP_PRED_U = 5, OP_PSOLVE = 6 };
+enum GemmOp { OP_SYRK = 1, OP_TRTRI_T = 2, OP_TRTRI_W = 3, OP_LAUUM = 4, OP_PRED_U = 5, OP_PSOLVE = 6, OP_CUPD = 7 };
 enum Lay { MK = 0, KM = 1 };
 
 struct GemmArgs {
@@ -781,7 +781,7 @@ template <typename T, int OP, int TM, int NW, bool WT = false>
 __device__ __forceinline__ void gemm_body(const GemmArgs& g, const int lin /*block index within this descriptor*/,
                                           unsigned char* lds) {
     constexpr int LA = (OP == OP_LAUUM) ? KM : MK;
-    constexpr int LB = (OP == OP_TRTRI_T || OP == OP_TRTRI_W || OP == OP_LAUUM) ? KM : MK;
+    constexpr int LB = (OP == OP_TRTRI_T || OP == OP_TRTRI_W || OP == OP_LAUUM || OP == OP_CUPD) ? KM : MK;
     constexpr int NT = NW * 64;
     constexpr int LD = TM + 16;     // = 16 (mod 32): the two k rows a 32-lane group reads hit disjoint banks
     constexpr int WTM = TM / (NW / 2), WTN = TM / 2;   // per-wave sub-tile
@@ -881,6 +881,20 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, const int lin /*blo
         B0 = Bb + (size_t)(c0 + jt) * TM * g.ldB + (size_t)c0 * TM; dB = TM;
         nkt = jt + 1;
         Ct = Cb + (size_t)R * TM * g.ldC + (size_t)(c0 + jt) * TM;
+    } else if constexpr (OP == OP_CUPD) {
+        // Rank-(panel) update of the progressive inverse (fill_sched.h: FILL_CUPD, wide form), tiles row-major over the rows
+        // R in [p2, ..) and the p3 tile columns from r_lo on:  V[R, c] (+)= sum_{kt = ks}^{p1 - 1} M[R, kt] W[kt, c],  the k tiles
+        // [p0, p1) = the panel; a column inside the panel starts at its own block row (zeros above) and is the first
+        // contribution to its tile.  (A from M, B from W, C in V.)
+        const int t = bid + g.t0;
+        const int R = g.p2 + t / g.p3, c = g.r_lo + t % g.p3;
+        const bool own = c >= g.p0;
+        const int ks = own ? c : g.p0;
+        A0 = Ab + (size_t)R * TM * g.ldA + (size_t)ks * TM; dA = TM;
+        B0 = Bb + (size_t)ks * TM * g.ldB + (size_t)c * TM; dB = (ptrdiff_t)TM * g.ldB;
+        nkt = g.p1 - ks;
+        Ct = Cb + (size_t)R * TM * g.ldC + (size_t)c * TM;
+        accumulate = !own;
     } else {
         // OP_PRED_U: U[m, r] = sum_{kt = 0}^{r} X[m, kt] W[r, kt]^T    (X = scaled cross covariance, n0pad x npad)
         const int r = g.nb - 1 - bid / g.p0, m = bid % g.p0;       // p0 = row tiles of X; longest k loops (large r) first
@@ -922,7 +936,7 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, const int lin /*blo
     // only add exact zeros: it skips the stage's fragment reads and MFMAs (one wave-uniform test per stage, nothing
     // else changes; bit-identical results: the zeros are stored zeros).  LAUUM / TRTRI_W: 24 of the 64 (wave, stage)
     // pairs of such a tile, TRTRI_T / PRED_U: 16.
-    constexpr bool HAS_TRI = OP != OP_SYRK;
+    constexpr bool HAS_TRI = OP != OP_SYRK && OP != OP_CUPD;
     const int tri_first = HAS_TRI ? (nkt - 1) * SPT : nst;
     // the wave is idle in the stages [dead_lo, dead_hi) of the k loop (two scalars per wave)
     int dead_lo = nst, dead_hi = nst;
@@ -981,7 +995,7 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, const int lin /*blo
         // holds its C tile in the accumulators from the start, so it looks ONE stage ahead (an fp64 stage is ~1.7 us of
         // MFMA work per workgroup: enough to cover an L2/HBM round trip with two workgroups per CU); deeper would spill.
         constexpr bool F64 = sizeof(T) == 8;
-        constexpr int PF = (OP == OP_SYRK) ? (F64 ? 1 : 2) : (TM == 64 ? (F64 ? 2 : 4) : 2);
+        constexpr int PF = (OP == OP_SYRK || (OP == OP_CUPD && NW == 4)) ? (F64 ? 1 : 2) : (TM == 64 ? (F64 ? 2 : 4) : 2);
         T ra[PF][EPT], rb[PF][EPT];
 #pragma unroll
         for (int h = 0; h < PF; ++h) {
@@ -1100,30 +1114,32 @@ __global__ __launch_bounds__(NW * 64, TM == 128 ? (NW == 8 ? 4 : 2) : 4) void ti
 using lcgp_fill::FillJob;
 using lcgp_fill::FillSet;
 
-template <typename T, int LA, int LB, bool NEG, bool WT = false>
+template <typename T, int LA, int LB, bool NEG, bool WT = false, int TNC = 64>
 __device__ __forceinline__ void rect_tile(const T* __restrict__ A0, int ldA, const T* __restrict__ B0, int ldB,
                                           T* __restrict__ Ct, int ldC, int nst, bool first, unsigned char* lds) {
-    constexpr int TMR = 128, TNC = 64, NT = 256;
+    // TNC = 64: 128 x 64 outputs (64 x 32 per wave);  TNC = 128 (a "wide" job, fill_sched.h): 128 x 128 outputs (64 x 64 per
+    // wave, 4x4 accumulators) -- half the operand traffic per flop, the shape of the 128-tile kernel on four waves
+    constexpr int TMR = 128, NT = 256, NJ_ = TNC / 32;
     constexpr int LDA = TMR + 16, LDB = TNC + 16;
     constexpr int EA = TMR * KT / NT, EB = TNC * KT / NT;
     T* As = (T*)lds;                   // [2][KT * LDA]
     T* Bs = As + 2 * KT * LDA;         // [2][KT * LDB]
     const int tid = body_tid(), lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm0 = (wave >> 1) * 64, wn0 = (wave & 1) * 32;
+    const int wm0 = (wave >> 1) * 64, wn0 = (wave & 1) * (TNC / 2);
     typedef typename Mfma<T>::acc_t acc_t;
-    acc_t acc[4][2];
+    acc_t acc[4][NJ_];
     if (first) {
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
+            for (int j = 0; j < NJ_; ++j)
 #pragma unroll
                 for (int e = 0; e < 4; ++e) acc[i][j][e] = 0;
     } else {
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
+            for (int j = 0; j < NJ_; ++j)
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
                     acc[i][j][e] = Ct[(size_t)(wm0 + i * 16 + Mfma<T>::row(lane, e)) * ldC + wn0 + j * 16 + (lane & 15)];
@@ -1159,18 +1175,18 @@ __device__ __forceinline__ void rect_tile(const T* __restrict__ A0, int ldA, con
 #pragma unroll
                 for (int kk = 0; kk < KT / 4; ++kk) {
                     const int kr = kk * 4 + (lane >> 4);
-                    T af[4], bf[2];
+                    T af[4], bf[NJ_];
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
                         const T v = as[kr * LDA + wm0 + swz_col<T>(i * 16, lane & 15, kk)];
                         af[i] = NEG ? -v : v;
                     }
 #pragma unroll
-                    for (int j = 0; j < 2; ++j) bf[j] = bs[kr * LDB + wn0 + swz_col<T>(j * 16, lane & 15, kk)];
+                    for (int j = 0; j < NJ_; ++j) bf[j] = bs[kr * LDB + wn0 + swz_col<T>(j * 16, lane & 15, kk)];
 #pragma unroll
                     for (int i = 0; i < 4; ++i)
 #pragma unroll
-                        for (int j = 0; j < 2; ++j) acc[i][j] = Mfma<T>::run(af[i], bf[j], acc[i][j]);
+                        for (int j = 0; j < NJ_; ++j) acc[i][j] = Mfma<T>::run(af[i], bf[j], acc[i][j]);
                     if (kk == 0 && s + h + 1 < nst) {
                         // stage s + h + 1 (register set (h + 1) & 1) into the other buffer, behind the first MFMAs
                         store_stage<T, LA, TMR, NT>(As + (h ^ 1) * KT * LDA, ra[h ^ 1], tid);
@@ -1188,14 +1204,14 @@ __device__ __forceinline__ void rect_tile(const T* __restrict__ A0, int ldA, con
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < NJ_; ++j)
 #pragma unroll
             for (int e = 0; e < 4; ++e)
                 gstore<WT>(Ct + (size_t)(wm0 + i * 16 + Mfma<T>::row(lane, e)) * ldC + wn0 + j * 16 + (lane & 15), (T)acc[i][j][e]);
 }
 
 // One block of a filler set: block b of the launch's filler range -> (job, component, tile) -> operands (fill_sched.h).
-template <typename T, bool WT = false>
+template <typename T, bool WT = false, bool WIDE = true /* false: the persistent launch, whose plans have no wide jobs */>
 __device__ __forceinline__ void fill_dispatch(const FillSet& fs, int b, unsigned char* lds) {
     int ji = 0;
     while (ji + 1 < fs.njobs && b >= fs.job[ji].nblk) { b -= fs.job[ji].nblk; ++ji; }
@@ -1220,7 +1236,21 @@ __device__ __forceinline__ void fill_dispatch(const FillSet& fs, int b, unsigned
     T* W = (T*)fs.W + (size_t)k * fs.mat;
     T* V = (T*)fs.V + (size_t)k * fs.mat;
     const int kb0 = jb.kb0, kb1 = jb.kb1;
-    if (jb.type == lcgp_fill::FILL_SYRK) {
+    if (WIDE && jb.wide) {
+        // 128 x 128 tiles (column pairs): the body of the wide tile kernel on the four waves of this launch, same enumeration
+        GemmArgs g;
+        g.sA = g.sB = g.sC = fs.mat; g.ldA = g.ldB = g.ldC = ld; g.nb = fs.nb / 2;
+        g.q = fs.q; g.t0 = jb.t0; g.skipq = 0;
+        if (jb.type == lcgp_fill::FILL_SYRK) {
+            g.A = fs.M; g.B = fs.M; g.C = fs.M;
+            g.p0 = kb0 / 2; g.p1 = kb1 / 2; g.p2 = jb.j0 / 2; g.p3 = jb.j1 / 2; g.r_lo = 0; g.r_hi = jb.R1;
+            gemm_body<T, OP_SYRK, 128, 4, WT>(g, b, lds);
+        } else {      // FILL_CUPD
+            g.A = fs.M; g.B = fs.W; g.C = fs.V;
+            g.p0 = kb0 / 2; g.p1 = kb1 / 2; g.p2 = jb.R0; g.p3 = (jb.j1 - jb.j0) / 2; g.r_lo = jb.j0 / 2; g.r_hi = 0;
+            gemm_body<T, OP_CUPD, 128, 4, WT>(g, b, lds);
+        }
+    } else if (jb.type == lcgp_fill::FILL_SYRK) {
         // M[R, j] -= sum_k M[R, k] M[j, k]^T over the block columns [kb0, kb1)
         int j = jb.j0;
         while (t >= jb.R1 - (j >> 1)) { t -= jb.R1 - (j >> 1); ++j; }
@@ -1257,7 +1287,7 @@ __device__ __forceinline__ void fill_dispatch(const FillSet& fs, int b, unsigned
     }
 }
 
-constexpr int FILL_LDS_BYTES = 2 * KT * (128 + 16 + 64 + 16) * 8;
+constexpr int FILL_LDS_BYTES = 2 * KT * (128 + 16 + 128 + 16) * 8;      // (the 128 x 128 filler tile)
 
 // filler jobs on their own (what the chain launches could not carry, and the tail of the progressive inverse)
 template <typename T>
@@ -1453,7 +1483,7 @@ struct Tile64 {          // 64x64 tile on 256 threads: wave (wm, wn) owns a 32x3
     }
 };
 
-template <typename T, bool WT = false>
+template <typename T, bool WT = false, bool WIDE = true>
 __device__ __forceinline__ void chain_step_body(const StepArgs& a, int b, unsigned char* lds) {
     typedef Tile64<T> TL;
     const int tid = body_tid(), lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1463,7 +1493,7 @@ __device__ __forceinline__ void chain_step_body(const StepArgs& a, int b, unsign
     const int nspecial = a.has_special * a.q;
     int t = -1, k = 0;
     if (b < nspecial) { t = 0; k = b; }
-    else if (b < nspecial + a.fs.nblk) { fill_dispatch<T, WT>(a.fs, b - nspecial, lds); return; }
+    else if (b < nspecial + a.fs.nblk) { fill_dispatch<T, WT, WIDE>(a.fs, b - nspecial, lds); return; }
     else {
         b -= nspecial + a.fs.nblk;
         if (b < (a.n_trmm - a.has_special) * a.q) { k = b % a.q; t = b / a.q + a.has_special; }
@@ -1711,7 +1741,7 @@ __global__ __launch_bounds__(256, 2) void dag_kernel(DagArgs a) {
             sa.trmm_r0 = sg.trmm_r0; sa.upd_r0 = sg.upd_r0;
             sa.logdet = a.logdet; sa.info = a.info;
             sa.fs.njobs = 0; sa.fs.nblk = 0;
-            chain_step_body<T, WT>(sa, b, lds);
+            chain_step_body<T, WT, false>(sa, b, lds);
             __builtin_amdgcn_s_setprio(0);
         } else if (sg.kind == lcgp_fill::S_TRAIL) {
             if (sg.with_leaf && b < q) {
@@ -1763,7 +1793,7 @@ __global__ __launch_bounds__(256, 2) void dag_kernel(DagArgs a) {
             fs.M = a.M; fs.W = a.W; fs.V = a.V; fs.mat = mat; fs.npad = npad; fs.nb = nbk; fs.q = q;
             fs.njobs = 1; fs.nblk = sg.job.nblk;
             fs.job[0] = sg.job;
-            fill_dispatch<T, WT>(fs, b, lds);
+            fill_dispatch<T, WT, false>(fs, b, lds);
         }
         // Every store of a body is write-through (gstore<true>): once every wave has drained its stores and the workgroup
         // has met, the results are in memory and one lane publishes them.  The next task is requested BEFORE the drain, so
@@ -2414,6 +2444,7 @@ inline lcgp_sched default_sched() {
                                    // trailing updates cut into near / far parts that alternate with the next panel's chain
     s.dag_spin_limit = 0;          // polls of one wait in that launch before it gives up (0 = 2,000,000, about two seconds)
     s.dag_flags = 0;               // protocol variants of that launch (measurement / diagnosis; see the header)
+    s.fill_wide = 0;               // 128x128 filler tiles (far columns of the trailing update, rank-256 updates of the inverse)
     return s;
 }
 
@@ -2421,7 +2452,7 @@ inline int check_sched(const lcgp_sched& s) {
     if (s.outer_blocks < 0 || s.outer_blocks > 64) return bad("sched.outer_blocks must be in [0, 64]");
     if (s.syrk_small_tiles < 0 || s.trtri_small_tiles < 0 || s.lauum_small_tiles < 0 || s.trtri_level_small < 0 ||
         s.fill_leaf < 0 || s.fill_step < 0 || s.leaf_in_wide < 0 || s.progressive_tiles < 0 || s.progressive_lauum < 0 ||
-        s.dag < 0 || s.dag > 2 || s.dag_spin_limit < 0)
+        s.dag < 0 || s.dag > 2 || s.dag_spin_limit < 0 || s.fill_wide < 0 || s.fill_wide > 1)
         return bad("sched fields must be >= 0");
     return 0;
 }
@@ -2513,6 +2544,7 @@ inline lcgp_fill::PlanParams plan_params(int dtype, int nb, int q, bool with_inv
     pp.syrk_small_tiles = sc.syrk_small_tiles; pp.fill_leaf = sc.fill_leaf; pp.fill_step = sc.fill_step;
     pp.leaf_in_wide = sc.leaf_in_wide;
     pp.interleaved = sc.dag == 2;
+    pp.fill_wide = sc.fill_wide != 0 && sc.dag == 0;
     pp.with_trtri = pp.interleaved && with_inverse && !(sc.dag_flags & 256);      // (256: the factorisation alone in the persistent launch)
     {
         const int nb2 = nb / 2;

@@ -1,6 +1,6 @@
 // Prints the launch plan of one factorisation (lcgp_amd/csrc/fill_sched.h: Planner) as text, for the CPU replay in
 // tests/test_fill_sched.py.  Host-only: g++ -std=c++17 -I lcgp_amd/csrc tests/native/dump_plan.cpp
-//   usage: dump_plan nb q ob syrk_small_tiles fill_leaf fill_step leaf_in_wide progressive [far_rides [with_dupd [dag [interleaved [with_trtri [trtri_all_small]]]]]]
+//   usage: dump_plan nb q ob syrk_small_tiles fill_leaf fill_step leaf_in_wide progressive [far_rides [with_dupd [dag [interleaved [with_trtri [trtri_all_small [fill_wide]]]]]]]
 // One line per launch ("L key=value ..."), followed by its filler jobs ("J ..."); with dag != 0 the task graph of the same
 // plan (DagBuilder) follows, one line per segment ("S key=value ... deps=seg:need,seg:need").
 #include <cstdio>
@@ -9,11 +9,11 @@
 #include "fill_sched.h"
 
 static void print_job(const lcgp_fill::FillJob& j) {
-    printf(" type=%d nblk=%d jt0=%d R0=%d R1=%d j0=%d j1=%d kb0=%d kb1=%d", j.type, j.nblk, j.t0, j.R0, j.R1, j.j0, j.j1, j.kb0, j.kb1);
+    printf(" type=%d nblk=%d jt0=%d R0=%d R1=%d j0=%d j1=%d kb0=%d kb1=%d wide=%d", j.type, j.nblk, j.t0, j.R0, j.R1, j.j0, j.j1, j.kb0, j.kb1, j.wide);
 }
 
 int main(int argc, char** argv) {
-    if (argc < 9 || argc > 15) { fprintf(stderr, "usage: dump_plan nb q ob syrk_small fill_leaf fill_step leaf_in_wide progressive\n"); return 2; }
+    if (argc < 9 || argc > 16) { fprintf(stderr, "usage: dump_plan nb q ob syrk_small fill_leaf fill_step leaf_in_wide progressive\n"); return 2; }
     lcgp_fill::PlanParams pp;
     pp.nb = atoi(argv[1]); pp.q = atoi(argv[2]); pp.ob = atoi(argv[3]); pp.syrk_small_tiles = atoi(argv[4]);
     pp.fill_leaf = atoi(argv[5]); pp.fill_step = atoi(argv[6]); pp.leaf_in_wide = atoi(argv[7]);
@@ -24,6 +24,7 @@ int main(int argc, char** argv) {
     pp.interleaved = argc > 12 && atoi(argv[12]) != 0;
     pp.with_trtri = argc > 13 && atoi(argv[13]) != 0;
     pp.trtri_all_small = argc > 14 ? atoi(argv[14]) : 0;
+    pp.fill_wide = argc > 15 && atoi(argv[15]) != 0;
     lcgp_fill::Planner plan(pp);
     plan.run();
     if (plan.failed) { printf("FAILED\n"); return 1; }

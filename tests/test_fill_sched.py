@@ -24,9 +24,9 @@ def dump_plan(tmp_path_factory):
                     os.path.join(ROOT, 'tests', 'native', 'dump_plan.cpp')], check=True)
 
     def run(nb, q, ob, syrk_small=2000, fill_leaf=248, fill_step=248, leaf_in_wide=1024, progressive=1, far_rides=1, with_dupd=1,
-            dag=0, interleaved=0, with_trtri=0, trtri_all_small=0):
+            dag=0, interleaved=0, with_trtri=0, trtri_all_small=0, fill_wide=0):
         out = subprocess.run([exe] + [str(v) for v in (nb, q, ob, syrk_small, fill_leaf, fill_step, leaf_in_wide, progressive,
-                                                       far_rides, with_dupd, dag, interleaved, with_trtri, trtri_all_small)],
+                                                       far_rides, with_dupd, dag, interleaved, with_trtri, trtri_all_small, fill_wide)],
                              check=True, capture_output=True, text=True).stdout
         assert 'FAILED' not in out
         launches = []
@@ -56,7 +56,7 @@ def dump_plan(tmp_path_factory):
                 assert len(deps) == d['ndeps']
                 d['deps'] = deps
                 d['jobs'] = [dict(type=d['type'], nblk=d['nblk'], t0=d['jt0'], R0=d['R0'], R1=d['R1'], j0=d['j0'], j1=d['j1'],
-                                  kb0=d['kb0'], kb1=d['kb1'])] if d['kind'] == 4 else []
+                                  kb0=d['kb0'], kb1=d['kb1'], wide=d.get('wide', 0))] if d['kind'] == 4 else []
                 segs.append(d)
         run.last_runs = runs
         return (launches, segs) if dag else launches
@@ -194,7 +194,32 @@ class Replay:
             ty, kb0, kb1 = jb['type'], jb['kb0'], jb['kb1']
             for t in range(jb['t0'], jb['t0'] + jb['nblk'] // q):
                 self.new_item()
-                if ty == 1:       # SYRK
+                if ty == 1 and jb.get('wide'):       # SYRK on 128 x 128 tiles: column pairs
+                    j, tt = jb['j0'], t
+                    assert j % 2 == 0 and jb['j1'] % 2 == 0
+                    while tt >= jb['R1'] - (j >> 1):
+                        tt -= jb['R1'] - (j >> 1)
+                        j += 2
+                    R = (j >> 1) + tt
+                    assert j < jb['j1'] and R < nb // 2
+                    v = self.rd('M', 2 * R, 2 * R + 2, j, j + 2) - self.rd('M', 2 * R, 2 * R + 2, kb0, kb1) @ self.rd('M', j, j + 2, kb0, kb1).T
+                    if R == j >> 1:     # the diagonal tile: only its lower blocks are data (the kernel rewrites the upper one too)
+                        self.wr('M', 2 * R, j, v[:, :TS])
+                        self.wr('M', 2 * R + 1, j + 1, v[TS:, TS:])
+                    else:
+                        self.wr('M', 2 * R, j, v)
+                elif ty == 3 and jb.get('wide'):     # CUPD on 128 x 128 tiles
+                    assert jb['j0'] % 2 == 0 and jb['j1'] % 2 == 0 and kb0 % 2 == 0
+                    nc = (jb['j1'] - jb['j0']) // 2
+                    R, j = jb['R0'] + t // nc, jb['j0'] + 2 * (t % nc)
+                    assert R < jb['R1']
+                    own = j >= kb0
+                    ks = j if own else kb0
+                    v = self.rd('M', 2 * R, 2 * R + 2, ks, kb1) @ self.rd('W', ks, kb1, j, j + 2)
+                    if not own:
+                        v = v + self.rd('V', 2 * R, 2 * R + 2, j, j + 2)
+                    self.wr('V', 2 * R, j, v)
+                elif ty == 1:       # SYRK
                     j, tt = jb['j0'], t
                     while tt >= jb['R1'] - (j >> 1):
                         tt -= jb['R1'] - (j >> 1)
@@ -430,6 +455,41 @@ def test_plan_without_inverse_replays_to_the_factor(dump_plan, nb, q, ob, kw):
     r = Replay(nb, q, seed=nb)
     r.run(launches)
     r.check(inverse=False)
+
+
+WIDE_CASES = [
+    (64, 8, 4, dict(fill_wide=1, fill_leaf=496, fill_step=496)),      # the headline size, eight components: one wide tile per CU
+    (64, 8, 4, dict(fill_wide=1, fill_leaf=992, fill_step=992)),
+    (64, 1, 4, dict(fill_wide=1)),
+    (64, 2, 4, dict(fill_wide=1, fill_leaf=496, fill_step=496, far_rides=0)),
+    (32, 6, 4, dict(fill_wide=1, fill_leaf=496, fill_step=496)),
+    (18, 1, 4, dict(fill_wide=1)),                                    # a short last panel
+    (10, 3, 4, dict(fill_wide=1, fill_leaf=40, fill_step=24)),
+    (24, 2, 8, dict(fill_wide=1)),
+    (12, 1, 2, dict(fill_wide=1)),
+    (14, 2, 6, dict(fill_wide=1)),
+    (16, 1, 3, dict(fill_wide=1)),                                    # odd panels: the jobs stay 128 x 64
+]
+
+
+@pytest.mark.parametrize('nb,q,ob,kw', WIDE_CASES)
+@pytest.mark.parametrize('mode', ['factor', 'inverse', 'inverse_and_ainv'])
+def test_plans_with_128x128_filler_tiles(dump_plan, nb, q, ob, kw, mode):
+    """FillJob::wide: the far columns of the trailing update and the rank-(64 ob) updates of the inverse as column pairs"""
+    prog = 0 if mode == 'factor' else 1
+    if prog and ob & (ob - 1):
+        pytest.skip('the progressive inverse needs a power-of-two panel (plan_params)')
+    launches = dump_plan(nb, q, ob, progressive=prog, with_dupd=1 if mode == 'inverse_and_ainv' else 0, **kw)
+    big = [jb for l in launches for jb in l['jobs'] if jb['type'] in (1, 3)]
+    assert all(bool(jb.get('wide')) == (ob % 2 == 0) for jb in big)
+    assert not any(jb.get('wide') for l in launches for jb in l['jobs'] if jb['type'] not in (1, 3))
+    cap = max(kw.get('fill_leaf', 248), kw.get('fill_step', 248))
+    for l in launches:
+        if l['kind'] in (1, 2):
+            assert sum(jb['nblk'] * (2 if jb.get('wide') else 1) for jb in l['jobs']) <= cap
+    r = Replay(nb, q, seed=5 * nb + q)
+    r.run(launches)
+    r.check(inverse=prog == 1, ainv=mode == 'inverse_and_ainv')
 
 
 def test_filler_capacity_is_respected(dump_plan):
