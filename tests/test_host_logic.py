@@ -367,7 +367,7 @@ def test_launch_plan_is_built_once_by_the_caller():
     import ctypes as C
     from lcgp_amd import _hip
     lib = _hip.load()
-    assert lib.lcgp_version() >= 300                      # the ABI of round 4 (plan arguments, lcgp_sched grew)
+    assert lib.lcgp_version() >= 310                      # the ABI of round 4 (plan arguments, lcgp_sched grew; 310: fill_wide)
     def build(n, q, inv, **fields):
         sc = _hip.default_sched()
         for k, v in fields.items():
