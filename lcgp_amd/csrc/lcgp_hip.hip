@@ -1114,12 +1114,10 @@ __global__ __launch_bounds__(NW * 64, TM == 128 ? (NW == 8 ? 4 : 2) : 4) void ti
 using lcgp_fill::FillJob;
 using lcgp_fill::FillSet;
 
-template <typename T, int LA, int LB, bool NEG, bool WT = false, int TNC = 64>
+template <typename T, int LA, int LB, bool NEG, bool WT = false>
 __device__ __forceinline__ void rect_tile(const T* __restrict__ A0, int ldA, const T* __restrict__ B0, int ldB,
                                           T* __restrict__ Ct, int ldC, int nst, bool first, unsigned char* lds) {
-    // TNC = 64: 128 x 64 outputs (64 x 32 per wave);  TNC = 128 (a "wide" job, fill_sched.h): 128 x 128 outputs (64 x 64 per
-    // wave, 4x4 accumulators) -- half the operand traffic per flop, the shape of the 128-tile kernel on four waves
-    constexpr int TMR = 128, NT = 256, NJ_ = TNC / 32;
+    constexpr int TMR = 128, TNC = 64, NT = 256, NJ_ = TNC / 32;
     constexpr int LDA = TMR + 16, LDB = TNC + 16;
     constexpr int EA = TMR * KT / NT, EB = TNC * KT / NT;
     T* As = (T*)lds;                   // [2][KT * LDA]
