@@ -54,6 +54,9 @@ def local_components(q: int, rank: int, world: int):
     return list(range(rank, q, world))
 
 
+_PINNED = {}      # (device index, length) -> pinned float64 row for the one device-to-host copy of an evaluation
+
+
 def reduce_to_host(t, group=None):
     """Sum the float64 torch tensor `t` over the ranks IN PLACE where it lives (device tensor + nccl: RCCL, no host
     round trip before the collective) and return it as a numpy array: exactly one device-to-host copy."""
@@ -66,6 +69,16 @@ def reduce_to_host(t, group=None):
         elif t.is_cuda:
             t = t.cpu()          # gloo rehearsal of a GPU job: the collective runs on host memory
         dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    if t.is_cuda:
+        # one asynchronous copy into a pinned row kept per (device, length) and one stream synchronisation: no pageable
+        # staging buffer and no allocation per evaluation
+        key = (t.device.index, t.numel())
+        pin = _PINNED.get(key)
+        if pin is None:
+            pin = _PINNED[key] = torch.empty(t.numel(), dtype=torch.float64).pin_memory()
+        pin.copy_(t.reshape(-1), non_blocking=True)
+        torch.cuda.current_stream(t.device).synchronize()
+        return pin.numpy().reshape(tuple(t.shape)).copy()
     return t.cpu().numpy()
 
 

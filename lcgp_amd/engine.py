@@ -67,8 +67,11 @@ class HotPathEngine:
             # two pinned staging rows used alternately: the H2D copy of one evaluation may still be in flight when the
             # host packs the next one (evaluate() itself synchronises, enqueue-style callers do not)
             self._theta_pin = [torch.zeros(self.q_local * self.tw + 1, dtype=torch.float64).pin_memory() for _ in range(2)]
+            self._theta_pin_np = [t.numpy() for t in self._theta_pin]      # the same memory, for host-side writes
             self._pin_event = [None, None]
             self._pin_next = 0
+            self._nll_ptrs = None
+            self._pack_ptrs = None
             self.out_dev = torch.zeros((self.q_local, self.ow), dtype=torch.float64, device=self.device)
             self.comp_dev = torch.as_tensor(np.asarray(comp_ids, np.int32)).to(self.device)
             self.partial_dev = torch.zeros(self.pw, dtype=torch.float64, device=self.device)
@@ -122,30 +125,46 @@ class HotPathEngine:
         _hip.check(self.lib.lcgp_plan_info(ph, *[C.byref(x) for x in v]), "lcgp_plan_info")
         return dict(zip(("launches", "segments", "tasks", "inverse_done"), (x.value for x in v)))
 
-    def upload_theta(self, theta_rows, guard=0.0):
+    def upload_theta(self, theta_rows, guard=0.0, stream=None):
         torch = self.torch
         theta_rows = np.asarray(theta_rows, dtype=np.float64).reshape(self.q_local, self.tw)
         i = self._pin_next
         self._pin_next ^= 1
-        if self._pin_event[i] is not None:
-            self._pin_event[i].synchronize()      # the copy that last read this staging buffer has completed
-        self._theta_pin[i][:-1].copy_(torch.from_numpy(theta_rows.reshape(-1)))
-        self._theta_pin[i][-1] = float(guard)
-        with torch.cuda.device(self.device):
+        ev = self._pin_event[i]
+        if ev is not None:
+            ev.synchronize()                      # the copy that last read this staging buffer has completed
+        else:
+            ev = self._pin_event[i] = torch.cuda.Event()
+        # (the pinned staging rows are written through their numpy views: no torch op per evaluation on the host side)
+        pin = self._theta_pin_np[i]
+        pin[:-1] = theta_rows.reshape(-1)
+        pin[-1] = float(guard)
+        if stream is None:
+            with torch.cuda.device(self.device):
+                self._theta_flat.copy_(self._theta_pin[i], non_blocking=True)
+                ev.record(torch.cuda.current_stream(self.device))
+        else:                                     # (the caller is inside the device context and holds the current stream)
             self._theta_flat.copy_(self._theta_pin[i], non_blocking=True)
-            ev = torch.cuda.Event()
-            ev.record(torch.cuda.current_stream(self.device))
-        self._pin_event[i] = ev
+            ev.record(stream)
         self._theta_last = theta_rows.copy()
 
-    def enqueue(self):
+    def _nll_args(self):
+        """the constant pointer arguments of lcgp_nll_grad as ctypes objects, made once (the tensors live as long as the engine)"""
+        if self._nll_ptrs is None:
+            self._nll_ptrs = tuple(self._p(t) for t in (self.x, self.Y, self.sr, self.theta_dev, self.workspace, self.out_dev))
+        return self._nll_ptrs
+
+    def enqueue(self, stream=None):
         """One pass of the hot path over the resident theta block (asynchronous)."""
+        if stream is not None:                    # (inside the device context already)
+            ph, pd = self.plan(True)
+            _hip.check(self.lib.lcgp_nll_grad(C.c_void_p(stream.cuda_stream), self.dtype, self.n, self.d, self.p, self.q_local,
+                                              *self._nll_args(), self._sched(), ph, pd), "lcgp_nll_grad")
+            return
         with self.torch.cuda.device(self.device):
             ph, pd = self.plan(True)
             _hip.check(self.lib.lcgp_nll_grad(self._stream(), self.dtype, self.n, self.d, self.p, self.q_local,
-                                              self._p(self.x), self._p(self.Y), self._p(self.sr),
-                                              self._p(self.theta_dev), self._p(self.workspace), self._p(self.out_dev),
-                                              self._sched(), ph, pd),
+                                              *self._nll_args(), self._sched(), ph, pd),
                        "lcgp_nll_grad")
 
     def evaluate(self, theta_rows):
@@ -157,12 +176,15 @@ class HotPathEngine:
     def evaluate_partial(self, theta_rows, guard=0.0):
         """theta rows -> this rank's share of the reduced vector, LEFT ON THE DEVICE (lcgp_pack_partial): the caller
         all-reduces it in place over the ranks (RCCL) and copies it to the host once.  `guard` travels in its last slot."""
-        self.upload_theta(theta_rows, guard)
-        self.enqueue()
-        with self.torch.cuda.device(self.device):
-            _hip.check(self.lib.lcgp_pack_partial(self._stream(), self.d, self.p, self.q_local, self.q_total,
-                                                  self._p(self.comp_dev), self._p(self.theta_dev), self._p(self.out_dev),
-                                                  self._p(self.guard_dev), self._p(self.partial_dev)), "lcgp_pack_partial")
+        if self._pack_ptrs is None:
+            self._pack_ptrs = tuple(self._p(t) for t in (self.comp_dev, self.theta_dev, self.out_dev, self.guard_dev, self.partial_dev))
+        torch = self.torch
+        with torch.cuda.device(self.device):      # one device context and one stream lookup per evaluation
+            st = torch.cuda.current_stream(self.device)
+            self.upload_theta(theta_rows, guard, st)
+            self.enqueue(st)
+            _hip.check(self.lib.lcgp_pack_partial(C.c_void_p(st.cuda_stream), self.d, self.p, self.q_local, self.q_total,
+                                                  *self._pack_ptrs), "lcgp_pack_partial")
         return self.partial_dev
 
     def is_current(self, theta_rows):

@@ -90,6 +90,7 @@ class LCGP:
         self._engine = None
         self._u_last = None          # unconstrained vector the factorisation in the workspace belongs to
         self._aux_override = {}
+        self._np_cache = {}          # name -> ((id, version), numpy copy) of constant tensor attributes (_const_np)
 
         self.x = self._verify_data_types(x)
         self.y = self._verify_data_types(y)
@@ -421,11 +422,31 @@ class LCGP:
             self._std = np.ones(int(self.p), F64)
             self._sum_log_r = 0.0
 
+    def _const_np(self, name):
+        """numpy view of a constant public attribute (a torch tensor: phi, diag_D), converted once per tensor VERSION -- the
+        evaluation loop reads these at every step, and an in-place change by a caller (torch bumps `_version`) or a new
+        tensor object invalidates the cached copy."""
+        t = getattr(self, name)
+        key = (id(t), getattr(t, '_version', None))
+        hit = self._np_cache.get(name)
+        if hit is None or hit[0] != key:
+            hit = (key, _np(t))
+            self._np_cache[name] = hit
+        return hit[1]
+
     def _theta_rows(self, sig_eff):
         lLmb, lLmb0, lnug = self.lLmb.numpy(), self.lLmb0.numpy(), self.lnugGPs.numpy()
-        phi, D = _np(self.phi), _np(self.diag_D)
-        rows = [np.concatenate([lLmb[k], [lLmb0[k], lnug[k], D[k]], phi[:, k] / sig_eff]) for k in self._local_ks]
-        return np.asarray(rows, F64).reshape(len(self._local_ks), int(self.d) + 3 + int(self.p))
+        phi, D = self._const_np('phi'), self._const_np('diag_D')
+        ks = self._local_ks
+        d = int(self.d)
+        rows = np.empty((len(ks), d + 3 + int(self.p)), F64)
+        if len(ks):
+            rows[:, :d] = lLmb[ks]
+            rows[:, d] = lLmb0[ks]
+            rows[:, d + 1] = lnug[ks]
+            rows[:, d + 2] = D[ks]
+            rows[:, d + 3:] = phi[:, ks].T / sig_eff
+        return rows
 
     def _zeros_on_device(self, shape):
         """A zero tensor where this rank's collectives run (a rank without components has no engine)."""

@@ -73,7 +73,7 @@ def main():
     print('list-schedule estimate of the launch: %.0f us' % sim_us)
     # sizeof(DagSeg): derive from the table span (padded to 256): use the known layout instead
     import struct
-    seg_ints = 6 + 16 + 16 + 7 + 4 + 2 + 4 + 4 + 9     # kind,t0,ntasks,per_comp,k_off,ndeps | dep | need | J.. | c_lo.. | t_first,t_count | r_lo,r_hi,trmm_r0,upd_r0 | job
+    seg_ints = 6 + 16 + 16 + 7 + 4 + 2 + 4 + 4 + 10    # kind,t0,ntasks,per_comp,k_off,ndeps | dep | need | J.. | c_lo.. | t_first,t_count | r_lo,r_hi,trmm_r0,upd_r0 | tri_* | job (FillJob: 10 ints)
     kinds = []
     for i in range(nseg):
         b = host[off_seg + i * seg_ints * 4: off_seg + (i + 1) * seg_ints * 4].tobytes()
