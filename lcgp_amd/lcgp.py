@@ -25,6 +25,7 @@ import torch
 
 from . import dist as _dist
 from .params import Parameter, SoftClip
+from .params import softclip_flat
 
 F64 = np.float64
 
@@ -91,6 +92,9 @@ class LCGP:
         self._u_last = None          # unconstrained vector the factorisation in the workspace belongs to
         self._aux_override = {}
         self._np_cache = {}          # name -> ((id, version), numpy copy) of constant tensor attributes (_const_np)
+        self._bounds_cache = None    # flat bounds of the three SoftClip blocks (_flat_transform)
+        self._es_cache = None        # diag_error_structure as arrays (_run_path)
+        self._jac_flat = None        # d constrained / d unconstrained of the evaluation in flight
 
         self.x = self._verify_data_types(x)
         self.y = self._verify_data_types(y)
@@ -434,8 +438,29 @@ class LCGP:
             self._np_cache[name] = hit
         return hit[1]
 
-    def _theta_rows(self, sig_eff):
-        lLmb, lLmb0, lnug = self.lLmb.numpy(), self.lLmb0.numpy(), self.lnugGPs.numpy()
+    def _flat_transform(self):
+        """constrained values and d constrained / d unconstrained of the three bounded blocks (lLmb, lLmb0, lnugGPs) in flat order,
+        in ONE vectorised pass (the per-parameter `transform.forward` / `.dforward` calls cost ~40 us of numpy dispatch per
+        evaluation, a tenth of a small configuration's step); same arithmetic element by element"""
+        q, d = int(self.q), int(self.d)
+        if not all(type(par.transform) is SoftClip for par in (self.lLmb, self.lLmb0, self.lnugGPs)):
+            return None                  # (a caller has replaced a transform: the per-parameter path serves any bijector)
+        key = tuple((id(par.transform), par.transform.low, par.transform.high) for par in (self.lLmb, self.lLmb0, self.lnugGPs))
+        if self._bounds_cache is None or self._bounds_cache[0] != key:
+            lo = np.concatenate([np.full(n_, par.transform.low, F64) for par, n_ in ((self.lLmb, q * d), (self.lLmb0, q), (self.lnugGPs, q))])
+            hi = np.concatenate([np.full(n_, par.transform.high, F64) for par, n_ in ((self.lLmb, q * d), (self.lLmb0, q), (self.lnugGPs, q))])
+            cc = np.concatenate([np.full(n_, par.transform._c, F64) for par, n_ in ((self.lLmb, q * d), (self.lLmb0, q), (self.lnugGPs, q))])
+            self._bounds_cache = (key, lo, hi, hi - lo, cc)
+        _, lo, hi, w, cc = self._bounds_cache
+        u = np.concatenate([self.lLmb.unconstrained.reshape(-1), self.lLmb0.unconstrained, self.lnugGPs.unconstrained])
+        return softclip_flat(u, lo, hi, w, cc)
+
+    def _theta_rows(self, sig_eff, constrained=None):
+        if constrained is None:
+            lLmb, lLmb0, lnug = self.lLmb.numpy(), self.lLmb0.numpy(), self.lnugGPs.numpy()
+        else:
+            q_, d_ = int(self.q), int(self.d)
+            lLmb, lLmb0, lnug = constrained[:q_ * d_].reshape(q_, d_), constrained[q_ * d_:q_ * d_ + q_], constrained[q_ * d_ + q_:]
         phi, D = self._const_np('phi'), self._const_np('diag_D')
         ks = self._local_ks
         d = int(self.d)
@@ -469,13 +494,19 @@ class LCGP:
         u_now = self._get_flat().copy()
         self._u_last = None
         n, d, p, q = int(self.n), int(self.d), int(self.p), int(self.q)
-        es = np.asarray(self.diag_error_structure, int)
+        es_key = tuple(self.diag_error_structure)
+        if self._es_cache is None or self._es_cache[0] != es_key:
+            es_arr = np.asarray(es_key, int)
+            self._es_cache = (es_key, es_arr, np.r_[0, np.cumsum(es_arr)[:-1]])
+        es, es_starts = self._es_cache[1], self._es_cache[2]
         ls2_b = np.repeat(self.lsigma2s.numpy(), es)
+        flat = self._flat_transform()
+        self._jac_flat = None if flat is None else flat[1]
         # a line-search trial may push lsigma2s far out: exp() overflowing to inf (psi / inf = 0) gives a huge finite value
         # that the optimiser rejects, as it does in the reference -- without numpy's warnings
         with np.errstate(over='ignore', divide='ignore'):
             sig_eff = np.exp(0.5 * ls2_b) / self._std
-            rows = self._theta_rows(sig_eff) if eng is not None else None
+            rows = self._theta_rows(sig_eff, None if flat is None else flat[0]) if eng is not None else None
         # Lock-step guard: every rank runs its own L-BFGS-B on the all-reduced numbers, no iterate is ever broadcast.
         # A hash of the parameter vector this rank is evaluating rides in the last slot of the vector; after the sum it must
         # equal world_size x the local one (integers below 2^32: exact in float64), or some rank has drifted -- then
@@ -531,7 +562,7 @@ class LCGP:
         nll = vec[0] + 0.5 * np.sum(self._ysq / sig_eff ** 2) + n / 2.0 * np.sum(ls2_b - 2.0 * np.log(self._std)) \
             - 0.5 * p * self._sum_log_r
         g_b = vec[2 + q * d + 2 * q:] + n / 2.0 - 0.5 * self._ysq / sig_eff ** 2
-        g_ls2 = np.add.reduceat(g_b, np.r_[0, np.cumsum(es)[:-1]])
+        g_ls2 = np.add.reduceat(g_b, es_starts)
         grad = np.concatenate([vec[2:2 + q * d + 2 * q], g_ls2])
         if self.submethod == 'rep':
             return float(nll / n), grad / n
@@ -542,6 +573,10 @@ class LCGP:
         if u is not None:
             self._set_flat(u)
         val, g = self._run_path()
+        if self._jac_flat is not None:       # the evaluation has formed it together with the constrained values (_flat_transform)
+            g = g.copy()
+            g[:self._jac_flat.size] *= self._jac_flat
+            return val, g
         jac = np.concatenate([self.lLmb.transform.dforward(self.lLmb.unconstrained).reshape(-1),
                               self.lLmb0.transform.dforward(self.lLmb0.unconstrained),
                               self.lnugGPs.transform.dforward(self.lnugGPs.unconstrained),

@@ -44,6 +44,15 @@ class SoftClip:
         return self._c * _sigmoid(self._w - _softplus(u - self.low)) * _sigmoid(u - self.low)
 
 
+def softclip_flat(u, lo, hi, w, c):
+    """SoftClip.forward and SoftClip.dforward of a FLAT vector whose elements have their own bounds (arrays lo, hi, w = hi - lo,
+    c = w / softplus(w)): one pass for the three bounded parameter blocks of an evaluation, the inner softplus shared.  Element
+    by element the same operations as the two methods above."""
+    t = u - lo
+    a = w - _softplus(t)
+    return hi - c * _softplus(a), c * _sigmoid(a) * _sigmoid(t)
+
+
 class Identity:
     low = -np.inf
     high = np.inf
