@@ -188,6 +188,26 @@ def test_softclip_matches_oracle_formulas():
         np.testing.assert_allclose(sc.forward(sc.inverse(v)), v, rtol=1e-9, atol=hi * 1e-15)
 
 
+def test_flat_softclip_pass_equals_the_per_parameter_transforms_bit_for_bit():
+    """The evaluation loop forms the constrained values and their derivatives of the three bounded blocks in one vectorised pass
+    (LCGP._flat_transform); element by element it is the arithmetic of SoftClip.forward / .dforward (lcgp.py:181-211 through the
+    bijector), so the results are the same bits -- and a model whose transform a caller has replaced takes the general path."""
+    x, y = synth.make_full(8, 40, 3, 5, 3)
+    m = LCGP(y=y, x=x, q=3)
+    rng = np.random.default_rng(3)
+    for par in (m.lLmb, m.lLmb0, m.lnugGPs):
+        par.unconstrained = rng.normal(0.0, 3.0, par.unconstrained.shape)
+    v, dv = m._flat_transform()
+    want_v = np.concatenate([m.lLmb.numpy().reshape(-1), m.lLmb0.numpy(), m.lnugGPs.numpy()])
+    want_d = np.concatenate([par.transform.dforward(par.unconstrained).reshape(-1) for par in (m.lLmb, m.lLmb0, m.lnugGPs)])
+    assert np.array_equal(v, want_v) and np.array_equal(dv, want_d)
+
+    class Shifted(SoftClip):          # any other bijector type
+        pass
+    m.lLmb0.transform = Shifted(m.lLmb0.transform.low, m.lLmb0.transform.high)
+    assert m._flat_transform() is None
+
+
 # ---- host assembly around the hot path, through the stand-in engine -----------------------------------------------
 @pytest.mark.parametrize('mode,kw', [('full', dict(q=3)), ('full', dict(q=2, diag_error_structure=[1, 3], robust_mean=False)),
                                      ('rep', {}), ('rep', dict(rep_standardize_ybar=False))])
