@@ -13,6 +13,7 @@
 #include <cstdlib>
 #include <vector>
 #include <cmath>
+#include <type_traits>
 
 typedef double d4 __attribute__((ext_vector_type(4)));
 constexpr int KT = 16;
@@ -33,7 +34,28 @@ __device__ __forceinline__ void store_stage(double* __restrict__ S, const double
     for (int e = 0; e < EPT; ++e) S[(kk + e) * LD + (m ^ ((kk + e) & 12))] = reg[e];
 }
 
-template <int TM, int TN, int WM, int WN, int PF, bool PRELOAD, int MINW>
+// operands stored with m contiguous (element (m, k) at P[k ld + m]: the layout of W in W^T W): 16-byte pieces per lane
+template <int TMX, int NT>
+__device__ __forceinline__ void load_stage_km(const double* __restrict__ P, int ld, int ks, double (&reg)[TMX * KT / NT], int tid) {
+    constexpr int EPT = TMX * KT / NT, TPK = TMX / EPT, NP = EPT / 2;
+    const int kq = tid / TPK, j = tid % TPK;
+    const double* src = P + (size_t)(ks + kq) * ld + j * 2;
+#pragma unroll
+    for (int pc = 0; pc < NP; ++pc)
+#pragma unroll
+        for (int e = 0; e < 2; ++e) reg[pc * 2 + e] = src[pc * (TMX / NP) + e];
+}
+template <int TMX, int NT>
+__device__ __forceinline__ void store_stage_km(double* __restrict__ S, const double (&reg)[TMX * KT / NT], int tid) {
+    constexpr int EPT = TMX * KT / NT, TPK = TMX / EPT, NP = EPT / 2, LD = TMX + 16;
+    const int kq = tid / TPK, j = tid % TPK;
+#pragma unroll
+    for (int pc = 0; pc < NP; ++pc)
+#pragma unroll
+        for (int e = 0; e < 2; ++e) S[kq * LD + ((j * 2 + pc * (TMX / NP)) ^ (kq & 12)) + e] = reg[pc * 2 + e];
+}
+
+template <int TM, int TN, int WM, int WN, int PF, bool PRELOAD, int MINW, bool KMAJ = false>
 __global__ __launch_bounds__(64 * WM * WN, MINW) void tile_kernel(const double* __restrict__ A, const double* __restrict__ B,
                                                                     double* __restrict__ C, int ldA, int ldB, int ldC, int nkt,
                                                                     int ntn) {
@@ -43,11 +65,22 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void tile_kernel(const double* 
     extern __shared__ __align__(16) unsigned char lds_raw[];
     double* As = (double*)lds_raw;            // [2][KT * LDA]
     double* Bs = As + 2 * KT * LDA;           // [2][KT * LDB]
+    const int tid = threadIdx.x;
     const int tm = blockIdx.x / ntn, tn = blockIdx.x % ntn;
-    const double* A0 = A + (size_t)tm * TM * ldA;
-    const double* B0 = B + (size_t)tn * TN * ldB;
+    const double* A0 = KMAJ ? A + (size_t)tm * TM : A + (size_t)tm * TM * ldA;
+    const double* B0 = KMAJ ? B + (size_t)tn * TN : B + (size_t)tn * TN * ldB;
+    auto ldst = [&](const double* P, int ld, int ks, auto& reg, auto tag) {
+        constexpr int X = decltype(tag)::value;
+        if constexpr (KMAJ) load_stage_km<X, NT>(P, ld, ks, reg, tid); else load_stage<X, NT>(P, ld, ks, reg, tid);
+    };
+    auto stst = [&](double* S, auto& reg, auto tag) {
+        constexpr int X = decltype(tag)::value;
+        if constexpr (KMAJ) store_stage_km<X, NT>(S, reg, tid); else store_stage<X, NT>(S, reg, tid);
+    };
+    std::integral_constant<int, TM> tgm;
+    std::integral_constant<int, TN> tgn;
     double* Ct = C + (size_t)tm * TM * ldC + (size_t)tn * TN;
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm0 = (wave / WN) * WTM, wn0 = (wave % WN) * WTN;
     d4 acc[MIM][MIN];
 #pragma unroll
@@ -62,20 +95,20 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void tile_kernel(const double* 
 #pragma unroll
     for (int h = 0; h < PF; ++h)
         if (h < nst) {
-            load_stage<TM, NT>(A0, ldA, h * KT, ra[h], tid);
-            load_stage<TN, NT>(B0, ldB, h * KT, rb[h], tid);
+            ldst(A0, ldA, h * KT, ra[h], tgm);
+            ldst(B0, ldB, h * KT, rb[h], tgn);
         }
     for (int s = 0; s < nst; s += PF) {
 #pragma unroll
         for (int h = 0; h < PF; ++h) {
             if (s + h < nst) {
                 const int buf = (PF & 1) ? ((s + h) & 1) : (h & 1);
-                store_stage<TM, NT>(As + buf * KT * LDA, ra[h], tid);
-                store_stage<TN, NT>(Bs + buf * KT * LDB, rb[h], tid);
+                stst(As + buf * KT * LDA, ra[h], tgm);
+                stst(Bs + buf * KT * LDB, rb[h], tgn);
                 __syncthreads();
                 if (s + h + PF < nst) {
-                    load_stage<TM, NT>(A0, ldA, (s + h + PF) * KT, ra[h], tid);
-                    load_stage<TN, NT>(B0, ldB, (s + h + PF) * KT, rb[h], tid);
+                    ldst(A0, ldA, (s + h + PF) * KT, ra[h], tgm);
+                    ldst(B0, ldB, (s + h + PF) * KT, rb[h], tgn);
                 }
                 const double* as = As + buf * KT * LDA;
                 const double* bs = Bs + buf * KT * LDB;
@@ -115,18 +148,19 @@ __global__ void fill_kernel(double* p, size_t n, unsigned seed) {
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
 
-template <int TM, int TN, int WM, int WN, int PF, bool PRELOAD, int MINW>
+template <int TM, int TN, int WM, int WN, int PF, bool PRELOAD, int MINW, bool KMAJ = false>
 double run(const char* name, const double* A, const double* B, double* C, int M, int N, int K, int extra_lds, int reps) {
-    auto kern = tile_kernel<TM, TN, WM, WN, PF, PRELOAD, MINW>;
+    auto kern = tile_kernel<TM, TN, WM, WN, PF, PRELOAD, MINW, KMAJ>;
+    const int ldA = KMAJ ? M : K, ldB = KMAJ ? N : K;
     const int lds = 2 * KT * (TM + 16 + TN + 16) * 8 + extra_lds;
     CK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     const int ntm = M / TM, ntn = N / TN;
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-    for (int w = 0; w < 2; ++w) hipLaunchKernelGGL(kern, dim3(ntm * ntn), dim3(64 * WM * WN), lds, 0, A, B, C, K, K, N, K / KT, ntn);
+    for (int w = 0; w < 2; ++w) hipLaunchKernelGGL(kern, dim3(ntm * ntn), dim3(64 * WM * WN), lds, 0, A, B, C, ldA, ldB, N, K / KT, ntn);
     CK(hipDeviceSynchronize());
     CK(hipEventRecord(e0));
-    for (int r = 0; r < reps; ++r) hipLaunchKernelGGL(kern, dim3(ntm * ntn), dim3(64 * WM * WN), lds, 0, A, B, C, K, K, N, K / KT, ntn);
+    for (int r = 0; r < reps; ++r) hipLaunchKernelGGL(kern, dim3(ntm * ntn), dim3(64 * WM * WN), lds, 0, A, B, C, ldA, ldB, N, K / KT, ntn);
     CK(hipEventRecord(e1));
     CK(hipEventSynchronize(e1));
     float ms;
@@ -172,7 +206,7 @@ int main() {
         check("128x128 8 waves", tile_kernel<128, 128, 4, 2, 1, true, 4>, 128, 128, 512, 2 * KT * (144 + 144) * 8);
         check("256x128 8 waves", tile_kernel<256, 128, 4, 2, 1, true, 2>, 256, 128, 512, 2 * KT * (272 + 144) * 8);
         check("256x128 8 waves PF 2", tile_kernel<256, 128, 4, 2, 2, true, 2>, 256, 128, 512, 2 * KT * (272 + 144) * 8);
-        hipFree(A); hipFree(B); hipFree(C);
+        CK(hipFree(A)); CK(hipFree(B)); CK(hipFree(C));
     }
     const int M = 8192, N = 8192;
     double *A, *B, *C;
@@ -195,6 +229,8 @@ int main() {
             run<128, 128, 4, 2, 2, false, 4>("128x128, 8 waves, PF 2, ONE workgroup per CU", A, B, C, M, N, K, 16 * 1024, reps);
             run<256, 128, 4, 2, 1, false, 2>("256x128, 8 waves, PF 1", A, B, C, M, N, K, 0, reps);
             run<256, 128, 4, 2, 2, false, 2>("256x128, 8 waves, PF 2", A, B, C, M, N, K, 0, reps);
+            run<128, 128, 4, 2, 2, false, 4, true>("128x128, 8 waves, PF 2, operands m-contiguous", A, B, C, M, N, K, 0, reps);
+            run<256, 128, 4, 2, 2, false, 2, true>("256x128, 8 waves, PF 2, operands m-contiguous", A, B, C, M, N, K, 0, reps);
         }
     }
     return 0;
