@@ -216,6 +216,13 @@ int main() {
     hipLaunchKernelGGL(fill_kernel, dim3(4096), dim3(256), 0, 0, B, (size_t)N * 2048, 7u);
     CK(hipMemset(C, 0, (size_t)M * N * 8));
     CK(hipDeviceSynchronize());
+    // the read-modify-write update at other panel widths (what wider outer panels / deferred far columns could buy per flop)
+    printf("---- C read-modify-write at other K\n");
+    run<128, 128, 4, 2, 1, true, 4>("128x128, 8 waves, PF 1 (library shape)", A, B, C, M, N, 128, 0, 20);
+    run<128, 128, 4, 2, 1, true, 4>("128x128, 8 waves, PF 1 (library shape)", A, B, C, M, N, 512, 0, 10);
+    run<128, 128, 4, 2, 1, true, 4>("128x128, 8 waves, PF 1 (library shape)", A, B, C, M, N, 1024, 0, 6);
+    run<256, 128, 4, 2, 1, true, 2>("256x128, 8 waves, PF 1", A, B, C, M, N, 512, 0, 10);
+    run<256, 128, 4, 2, 1, true, 2>("256x128, 8 waves, PF 1", A, B, C, M, N, 1024, 0, 6);
     for (int pass = 0; pass < 2; ++pass) {
         const int K = pass == 0 ? 256 : 2048, reps = pass == 0 ? 20 : 4;
         printf("---- K = %d, %s\n", K, pass == 0 ? "C read-modify-write (the trailing update)" : "C written once (the long products)");
