@@ -100,6 +100,11 @@ typedef struct lcgp_sched {
                                rank-256 updates of the progressive inverse are 128x128 (the shape of the wide tile kernel, on
                                the four waves of a chain launch) instead of 128x64; fill_leaf / fill_step keep counting
                                128x64 tiles, such a tile takes two of them (0 with `dag`) */
+    int hosted;             /* 1 = hosted panels: ONE launch per outer panel of 256 columns in which one workgroup per component
+                               factors and inverts the panel's whole diagonal block while all other workgroups run deferred
+                               trailing updates (256x128 tiles, long K), followed by the panel solve of the rows below and the
+                               rank-256 update of the next panel's columns (n padded must be a multiple of 256, at least 512) */
+    int hosted_defer;       /* hosted panels: a column panel receives the finished panels in groups of this many (2) */
 } lcgp_sched;
 int lcgp_sched_default(lcgp_sched* sched /*host out*/);
 

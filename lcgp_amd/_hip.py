@@ -25,7 +25,8 @@ class Sched(C.Structure):
     _fields_ = [("outer_blocks", C.c_int), ("syrk_small_tiles", C.c_int), ("trtri_small_tiles", C.c_int),
                 ("lauum_small_tiles", C.c_int), ("trtri_level_small", C.c_int), ("fill_leaf", C.c_int),
                 ("fill_step", C.c_int), ("leaf_in_wide", C.c_int), ("progressive_tiles", C.c_int), ("progressive_far", C.c_int), ("progressive_lauum", C.c_int),
-                ("dag", C.c_int), ("dag_spin_limit", C.c_int), ("dag_flags", C.c_int), ("fill_wide", C.c_int)]
+                ("dag", C.c_int), ("dag_spin_limit", C.c_int), ("dag_flags", C.c_int), ("fill_wide", C.c_int),
+                ("hosted", C.c_int), ("hosted_defer", C.c_int)]
 
 
 # every symbol include/lcgp_hip.h declares: name -> (restype, argtypes)

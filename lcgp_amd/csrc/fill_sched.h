@@ -1166,6 +1166,91 @@ class DagScheduler {
     double makespan_us = 0.0;
 };
 
+// ---------------------------------------------------------------------------------------------------
+// Hosted panels (lcgp_hip.hip: host_kernel).  Per outer panel P of `ob` = 4 block columns three launches:
+//   A(P)  q chain workgroups factor the panel's whole diagonal block (and invert it), all other workgroups run DEFERRED
+//         trailing updates: jobs (column panels, K range) -- 256 x 128 tiles of  M[R, c] -= sum_{k0 <= k < k1} L[R, k] L[c, k]^T;
+//   B(P)  the panel solve of the rows below,  L[R, P] = X[R, P] W_PP^T  (X = the updated panel: in the scratch matrix V, where
+//         C(P-1) left it; panel 0 is solved in place, one launch per block column from the right);
+//   C(P)  the rank-(64 ob) update of the NEXT panel's columns only (its diagonal block back into M, the rows below into V).
+// Left-looking at the outer level: column panel c receives the finished panels in groups of `defer` (one visit with
+// K = 64 ob defer instead of `defer` read-modify-write passes), staggered so that every launch carries about the same
+// share: column c is visited by A(P) when (c - 1 - P) is a multiple of `defer` -- which makes the visit of A(c - 1), the
+// last chance before the column's own chain, a regular one.  tests/test_fill_sched.py replays the plan on numpy matrices.
+// ---------------------------------------------------------------------------------------------------
+constexpr int HOST_NJ = 16;
+
+struct HostJob {
+    int cp0, ncp;        // column panels cp0 .. cp0 + ncp - 1 (256 columns = two 128-column tiles each)
+    int k0, k1;          // K range in 64-blocks
+    int np;              // panels per side: column panel c has the 256-row blocks c .. np - 1
+    int nblk;            // blocks = tiles x components (component = fastest index); tiles column panel by column panel,
+                         // row block by row block, the two column tiles of a row block adjacent
+};
+
+inline long host_job_tiles(int cp0, int ncp, int np) {
+    long n = 0;
+    for (int c = cp0; c < cp0 + ncp; ++c) n += 2L * (np - c);
+    return n;
+}
+
+struct HostPanel {
+    HostPanel() { memset((void*)this, 0, sizeof(*this)); }
+    int J, pe, ne;       // the panel's block columns [J, pe), the next panel's [pe, ne)  (ne = pe: the last panel)
+    int njobs;
+    int nhost;           // blocks of all jobs
+    HostJob job[HOST_NJ];
+};
+
+class HostPlanner {
+ public:
+    // nb: 64-blocks per side (a multiple of ob = 4), q components, defer >= 1
+    HostPlanner(int nb_, int q_, int defer_) : nb(nb_), q(q_), defer(defer_ < 1 ? 1 : defer_) {}
+    std::vector<HostPanel> panels;
+    bool failed = false;
+    static bool applicable(int nb) { return nb >= 8 && nb % 4 == 0; }
+
+    void run() {
+        const int ob = 4, np = nb / ob;
+        std::vector<int> applied(np, 0);          // panels [0, applied[c]) have been applied to column panel c
+        for (int P = 0; P < np; ++P) {
+            HostPanel hp;
+            hp.J = P * ob; hp.pe = hp.J + ob; hp.ne = P + 1 < np ? hp.pe + ob : hp.pe;
+            for (int c = P + 1; c < np; ++c) {
+                if (applied[c] >= P) continue;
+                if (c != P + 1 && (c - 1 - P) % defer != 0) continue;
+                // merge with the previous job when it is the column panel next to it with the same K range
+                if (hp.njobs > 0) {
+                    HostJob& pj = hp.job[hp.njobs - 1];
+                    if (pj.cp0 + pj.ncp == c && pj.k0 == applied[c] * ob) {
+                        ++pj.ncp;
+                        applied[c] = P;
+                        continue;
+                    }
+                }
+                if (hp.njobs >= HOST_NJ) continue;        // (stays pending: a later launch takes it with a longer K)
+                HostJob& j = hp.job[hp.njobs++];
+                j.cp0 = c; j.ncp = 1; j.k0 = applied[c] * ob; j.k1 = P * ob; j.np = np;
+                applied[c] = P;
+            }
+            if (P + 1 < np && applied[P + 1] != P) { failed = true; return; }
+            // longest K first
+            for (int i = 1; i < hp.njobs; ++i)
+                for (int j = i; j > 0 && hp.job[j].k1 - hp.job[j].k0 > hp.job[j - 1].k1 - hp.job[j - 1].k0; --j)
+                    std::swap(hp.job[j], hp.job[j - 1]);
+            for (int i = 0; i < hp.njobs; ++i) {
+                hp.job[i].nblk = (int)(host_job_tiles(hp.job[i].cp0, hp.job[i].ncp, np) * q);
+                hp.nhost += hp.job[i].nblk;
+            }
+            panels.push_back(hp);
+            if (P + 1 < np) applied[P + 1] = P + 1;      // C(P)
+        }
+    }
+
+ private:
+    int nb, q, defer;
+};
+
 }  // namespace lcgp_fill
 
 #endif

@@ -694,6 +694,9 @@ struct GemmArgs {
     int r_lo = 0, r_hi = 0;                     // OP_SYRK: tile rows [max(column, r_lo), r_hi) of every tile column (r_hi = 0: to nb)
     const void* bvec = nullptr;                 // OP_LAUUM on 128-tiles: b (npad per component) and the partial buffer of
     double* part = nullptr;                     // z = A^-1 b, [component][tile][2][128]; null = no fused product
+    void* C2 = nullptr; int r_c2 = 0;           // OP_SYRK: tiles of the rows >= r_c2 are STORED into this matrix instead of C
+                                                // (hosted panels: the rows below the next diagonal block go to the scratch
+                                                // matrix, from where the out-of-place panel solve reads them)
 };
 
 // one K-stage (KT = 16 k values) of a TM-row operand tile: global -> registers -> LDS [k][m], ld = TM + 16;
@@ -815,6 +818,7 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, const int lin /*blo
 
     // ---- per-op tile decode: A0/B0 = first operand tiles, dA/dB = pointer step per kt, nkt, C tile ----
     const T* A0; const T* B0; T* Ct;
+    T* Cs = nullptr;            // OP_SYRK: where the tile is stored when not in place (GemmArgs::C2)
     ptrdiff_t dA, dB;           // signed: some ops walk their k tiles downwards (see below)
     int nkt;
     double alpha = 1.0;
@@ -832,6 +836,7 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, const int lin /*blo
         B0 = Bb + (size_t)c * TM * g.ldB + (size_t)g.p0 * TM; dB = TM;
         nkt = g.p1 - g.p0;
         Ct = Cb + (size_t)r * TM * g.ldC + (size_t)c * TM;
+        Cs = (g.C2 && r >= g.r_c2) ? (T*)g.C2 + (size_t)k * g.sC + (size_t)r * TM * g.ldC + (size_t)c * TM : Ct;
         alpha = -1.0; accumulate = true;
     } else if constexpr (OP == OP_TRTRI_T || OP == OP_TRTRI_W) {
         // level with block size mb = p0: pair pr covers block rows [2 pr mb, 2 pr mb + 2 mb).
@@ -876,7 +881,10 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, const int lin /*blo
         // jt = p1, R = p2 + bid; W_PP = the panel's block of L^-1 (lower triangular: the last k tile is its diagonal tile).
         // The tile it overwrites is its own last A operand: every global read of the k loop has been consumed through LDS
         // before the loop's last barrier, the stores come after it.
-        const int R = g.p2 + bid, jt = g.p1, c0 = g.p0;
+        // p3 > 0: OUT of place (A in another matrix than C) and all p3 column tiles of the panel in ONE launch, the longest
+        // K loops first: tile bid = (p3 - 1 - jt) * rows + (R - p2), rows = nb - p2.
+        const int rows = g.nb - g.p2;
+        const int R = g.p2 + (g.p3 > 0 ? bid % rows : bid), jt = g.p3 > 0 ? g.p3 - 1 - bid / rows : g.p1, c0 = g.p0;
         A0 = Ab + (size_t)R * TM * g.ldA + (size_t)c0 * TM; dA = TM;
         B0 = Bb + (size_t)(c0 + jt) * TM * g.ldB + (size_t)c0 * TM; dB = TM;
         nkt = jt + 1;
@@ -1031,7 +1039,7 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, const int lin /*blo
             for (int e = 0; e < 4; ++e) {
                 const int row = wm0 + mi * 16 + Mfma<T>::row(lane, e);
                 const int col = wn0 + ni * 16 + (lane & 15);
-                T* dst = Ct + (size_t)row * g.ldC + col;
+                T* dst = (OP == OP_SYRK ? Cs : Ct) + (size_t)row * g.ldC + col;
                 if constexpr (OP == OP_SYRK && TM == 128) {
                     if (g.skipq && bid + g.t0 == 0 && row < TS && col < TS) continue;
                 }
@@ -1608,6 +1616,203 @@ __global__ __launch_bounds__(256, 2) void wide_leaf_kernel(GemmArgs g, T* __rest
         return;
     }
     gemm_body<T, OP_SYRK, TM, 4>(g, blockIdx.x - q, lds);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Hosted panels (lcgp_sched.hosted; fill_sched.h: HostPlanner).  ONE launch per outer panel of four block columns:
+//   * the first q workgroups (one per component, four of their eight waves) factor the panel's WHOLE 256 x 256 diagonal block
+//     -- the four 64 x 64 diagonal blocks (leaf_body), the six solve tiles between them with their left-looking updates,
+//     and the block's complete inverse W_PP (the first two levels of the triangular inverse) -- with no other workgroup
+//     involved: the latency chain of a panel is one workgroup's program instead of five dependent launches;
+//   * every other workgroup runs DEFERRED trailing updates, 256 x 128 tiles on eight waves with a long K loop:
+//     M[R, c] -= sum_{k in [k0, k1)} L[R, k] L[c, k]^T for column panels c to the right of the current one and the finished
+//     panels k the column has not received yet (left-looking at the outer level: a column is visited once per two or more
+//     panels instead of once per panel).  Nothing here touches what the chain workgroups read or write.
+// No workgroup of the launch depends on another one; stream order between launches is the only ordering.  The kernel is
+// compiled for ONE workgroup of 512 threads per CU (256 registers per lane: what the diagonal-block code needs; the
+// 256 x 128 tile holds 97 % of the two-workgroup rate of the 128 x 128 kernel that way, tools/tile_shape_bench.hip).
+// Behind it per panel: the panel solve of the rows below (OP_PSOLVE with W_PP) and the rank-256 update of the NEXT panel's
+// columns only (OP_SYRK), both short wide launches.
+// ---------------------------------------------------------------------------------------------------
+using lcgp_fill::HostJob;
+using lcgp_fill::HostPanel;
+using lcgp_fill::HOST_NJ;
+
+struct HostArgs {
+    void* M; void* W; void* V; size_t mat; int npad, nb, q;
+    int J, pe;                      // the panel's block columns [J, pe)
+    double* logdet; int* info;
+    int njobs;
+    HostJob job[HOST_NJ];
+};
+
+constexpr int HOST_TM = 256, HOST_TN = 128, HOST_NT = 512;
+template <typename T>
+constexpr int host_tile_lds() { return 2 * KT * (HOST_TM + 16 + HOST_TN + 16) * (int)sizeof(T); }
+
+template <typename T>
+__device__ __forceinline__ void host_tile_body(const HostArgs& a, int b, unsigned char* lds) {
+    constexpr int LDA = HOST_TM + 16, LDB = HOST_TN + 16;
+    constexpr int EA = HOST_TM * KT / HOST_NT, EB = HOST_TN * KT / HOST_NT;
+    int ji = 0;
+    while (ji + 1 < a.njobs && b >= a.job[ji].nblk) { b -= a.job[ji].nblk; ++ji; }
+    const HostJob jb = a.job[ji];
+    const int k = b % a.q;
+    int t = b / a.q, cp = jb.cp0;
+    while (t >= 2 * (jb.np - cp)) { t -= 2 * (jb.np - cp); ++cp; }
+    const int R = cp + (t >> 1), ct = 2 * cp + (t & 1);            // 256-row block, 128-column tile
+    const int ld = a.npad;
+    T* Mk = (T*)a.M + (size_t)k * a.mat;
+    const T* A0 = Mk + (size_t)R * HOST_TM * ld + (size_t)jb.k0 * TS;
+    const T* B0 = Mk + (size_t)ct * HOST_TN * ld + (size_t)jb.k0 * TS;
+    T* Ct = Mk + (size_t)R * HOST_TM * ld + (size_t)ct * HOST_TN;
+    const int nst = (jb.k1 - jb.k0) * (TS / KT);
+    T* As = (T*)lds;                    // [2][KT * LDA]
+    T* Bs = As + 2 * KT * LDA;          // [2][KT * LDB]
+    const int tid = body_tid(), lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm0 = (wave >> 1) * 64, wn0 = (wave & 1) * 64;
+    // the second column tile of the panel's own row block: its rows 0 .. 127 lie above the diagonal (never read by anyone)
+    const bool live = !(R == cp && (t & 1) && wm0 < 128);
+    typedef typename Mfma<T>::acc_t acc_t;
+    acc_t acc[4][4];
+    if (live) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    acc[i][j][e] = Ct[(size_t)(wm0 + i * 16 + Mfma<T>::row(lane, e)) * ld + wn0 + j * 16 + (lane & 15)];
+    }
+    T ra[EA], rb[EB];
+    load_stage<T, MK, HOST_TM, HOST_NT>(A0, ld, 0, ra, tid);
+    load_stage<T, MK, HOST_TN, HOST_NT>(B0, ld, 0, rb, tid);
+    const int l15 = lane & 15;
+    for (int s = 0; s < nst; ++s) {
+        const int buf = s & 1;
+        store_stage<T, MK, HOST_TM, HOST_NT>(As + buf * KT * LDA, ra, tid);
+        store_stage<T, MK, HOST_TN, HOST_NT>(Bs + buf * KT * LDB, rb, tid);
+        __syncthreads();
+        if (s + 1 < nst) {
+            load_stage<T, MK, HOST_TM, HOST_NT>(A0, ld, (s + 1) * KT, ra, tid);
+            load_stage<T, MK, HOST_TN, HOST_NT>(B0, ld, (s + 1) * KT, rb, tid);
+        }
+        if (live) {
+            const T* as = As + buf * KT * LDA;
+            const T* bs = Bs + buf * KT * LDB;
+#pragma unroll
+            for (int kk = 0; kk < KT / 4; ++kk) {
+                const int kr = kk * 4 + (lane >> 4);
+                T af[4], bf[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) af[i] = -as[kr * LDA + wm0 + swz_col<T>(i * 16, l15, kk)];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) bf[j] = bs[kr * LDB + wn0 + swz_col<T>(j * 16, l15, kk)];
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[i][j] = Mfma<T>::run(af[i], bf[j], acc[i][j]);
+            }
+        }
+    }
+    if (live) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    Ct[(size_t)(wm0 + i * 16 + Mfma<T>::row(lane, e)) * ld + wn0 + j * 16 + (lane & 15)] = (T)acc[i][j][e];
+    }
+}
+
+// The diagonal block [J, pe) x [J, pe) of component k on ONE workgroup of 256 threads: L in place, its 64 x 64 diagonal-block
+// inverses and then the whole block inverse W_PP in W (scratch: the same block of V).  Left-looking inside the block: the tile
+// (r, c) receives the columns J .. c-1 when its own column is factored; the diagonal tiles are updated as soon as a column
+// of their row is final, so that the next diagonal block is ready when its turn comes.
+template <typename T>
+__device__ __forceinline__ void chain_panel_body(unsigned char* lds, int k, const HostArgs& a) {
+    typedef Tile64<T> TL;
+    const int ld = a.npad, J = a.J, pe = a.pe;
+    T* Mk = (T*)a.M + (size_t)k * a.mat;
+    const T* Wk = (const T*)a.W + (size_t)k * a.mat;
+    T* F = (T*)lds;                        // TS * LD elements (= the four staging buffers of TL::mma)
+    T* Bst = F + TS * TL::LD;              // two B staging buffers behind it
+#pragma unroll 1
+    for (int c = J; c < pe; ++c) {
+        leaf_body<T>(lds, k, (T*)a.M, (T*)a.W, a.mat, a.npad, c, a.logdet, a.info);
+        __syncthreads();                   // L_cc, W_cc stored; the LDS of the diagonal block is free
+#pragma unroll 1
+        for (int r = c + 1; r < pe; ++r) {
+            // (the thread index is taken per tile: taken once in front of the loops, every lane-dependent address of the tile
+            // code is hoisted there and kept alive across the diagonal block, which needs the whole register file itself)
+            const int tid = body_tid(), lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+            const int wm0 = (wave >> 1) * 32, wn0 = (wave & 1) * 32;
+            T* Ct = Mk + (size_t)r * TS * ld + (size_t)c * TS;
+            typename TL::acc_t acc[2][2];
+            T pw[TL::SPT][TL::EPT];
+            TL::fetch(pw, Wk + (size_t)c * TS * ld + (size_t)c * TS, ld, tid);
+            TL::load(acc, Ct, ld, lane, wm0, wn0);
+#pragma unroll 1
+            for (int j = J; j < c; ++j)
+                TL::template mma<true>(acc, Mk + (size_t)r * TS * ld + (size_t)j * TS, ld,
+                                       Mk + (size_t)c * TS * ld + (size_t)j * TS, ld, (T*)lds, tid, lane, wm0, wn0);
+            __syncthreads();               // the staging buffers become F
+            TL::to_operand(acc, F, lane, wm0, wn0);
+            TL::zero(acc);
+            TL::template mma_a_lds<false>(acc, F, pw, Bst, tid, lane, wm0, wn0);
+            TL::template store<false>(acc, Ct, ld, lane, wm0, wn0);         // L[r, c]
+            T* Dt = Mk + (size_t)r * TS * ld + (size_t)r * TS;
+            typename TL::acc_t dacc[2][2];
+            TL::load(dacc, Dt, ld, lane, wm0, wn0);
+            __syncthreads();               // every read of the old F has been issued and consumed
+            TL::to_operand(acc, F, lane, wm0, wn0);
+            __syncthreads();
+            TL::template mma_ab_lds<true>(dacc, F, lane, wm0, wn0);
+            TL::template store<false>(dacc, Dt, ld, lane, wm0, wn0);
+            __syncthreads();               // F is free; the stores are visible to the workgroup
+        }
+    }
+    // W_PP: pairs of 64-blocks, then the pair of 128-blocks (the bodies of the level-parallel triangular inverse)
+    GemmArgs g;
+    g.sA = g.sB = g.sC = a.mat; g.ldA = g.ldB = g.ldC = ld; g.nb = a.nb;
+    g.q = 1; g.t0 = 0; g.skipq = 1; g.p3 = 0;
+    T* Vk = (T*)a.V + (size_t)k * a.mat;
+#pragma unroll 1
+    for (int mb = 1; mb < pe - J; mb *= 2) {
+        int np = 0;
+        for (int pr = J / (2 * mb); 2 * pr * mb + mb < pe; ++pr) ++np;      // pairs whose second half exists
+        g.p0 = mb; g.p1 = np; g.p2 = J / (2 * mb);
+        g.A = Mk; g.B = Wk; g.C = Vk;
+#pragma unroll 1
+        for (int t = 0; t < np * mb * mb; ++t) {
+            gemm_body<T, OP_TRTRI_T, 64, 4>(g, t, lds);
+            __syncthreads();
+        }
+        g.A = Wk; g.B = Vk; g.C = (void*)Wk;
+#pragma unroll 1
+        for (int t = 0; t < np * mb * mb; ++t) {
+            gemm_body<T, OP_TRTRI_W, 64, 4>(g, t, lds);
+            __syncthreads();
+        }
+    }
+}
+
+template <typename T>
+constexpr int host_lds_bytes() {
+    return host_tile_lds<T>() > LEAF_LDS_BYTES ? host_tile_lds<T>() : LEAF_LDS_BYTES;
+}
+
+template <typename T>
+__global__ __launch_bounds__(HOST_NT, 2) void host_kernel(HostArgs a) {
+    __shared__ __align__(16) unsigned char lds[host_lds_bytes<T>()];
+    if ((int)blockIdx.x < a.q) {
+        // waves 4 .. 7 of a chain workgroup leave at once: a barrier only counts the waves that are still running
+        if (threadIdx.x >= 256) return;
+        chain_panel_body<T>(lds, blockIdx.x, a);
+        return;
+    }
+    host_tile_body<T>(a, blockIdx.x - a.q, lds);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -2443,6 +2648,9 @@ inline lcgp_sched default_sched() {
     s.dag_spin_limit = 0;          // polls of one wait in that launch before it gives up (0 = 2,000,000, about two seconds)
     s.dag_flags = 0;               // protocol variants of that launch (measurement / diagnosis; see the header)
     s.fill_wide = 0;               // 128x128 filler tiles (far columns of the trailing update, rank-256 updates of the inverse)
+    s.hosted = 0;                  // 1 = hosted panels (host_kernel): one launch per outer panel whose chain workgroups share it
+                                   // with deferred trailing updates
+    s.hosted_defer = 2;            // ... a column panel receives the finished panels in groups of this many
     return s;
 }
 
@@ -2450,7 +2658,8 @@ inline int check_sched(const lcgp_sched& s) {
     if (s.outer_blocks < 0 || s.outer_blocks > 64) return bad("sched.outer_blocks must be in [0, 64]");
     if (s.syrk_small_tiles < 0 || s.trtri_small_tiles < 0 || s.lauum_small_tiles < 0 || s.trtri_level_small < 0 ||
         s.fill_leaf < 0 || s.fill_step < 0 || s.leaf_in_wide < 0 || s.progressive_tiles < 0 || s.progressive_lauum < 0 ||
-        s.dag < 0 || s.dag > 2 || s.dag_spin_limit < 0 || s.fill_wide < 0 || s.fill_wide > 1)
+        s.dag < 0 || s.dag > 2 || s.dag_spin_limit < 0 || s.fill_wide < 0 || s.fill_wide > 1 || s.hosted < 0 || s.hosted > 1 ||
+        s.hosted_defer < 1 || s.hosted_defer > 16)
         return bad("sched fields must be >= 0");
     return 0;
 }
@@ -2621,6 +2830,54 @@ inline int check_plan(const void* plan_host, int dtype, int n, int q, bool with_
     return 0;
 }
 
+// Hosted panels (see host_kernel): per outer panel the launch that factors its diagonal block beside deferred trailing
+// updates, the panel solve of the rows below and the rank-256 update of the next panel's columns.
+template <typename T>
+int do_potrf_hosted(hipStream_t st, const Ws& w, const lcgp_sched& sc) {
+    T* M = (T*)(w.base + w.off_M);
+    T* W = (T*)(w.base + w.off_W);
+    T* V = (T*)(w.base + w.off_V);
+    lcgp_fill::HostPlanner plan(w.nb, w.q, sc.hosted_defer);
+    plan.run();
+    if (plan.failed) return bad("internal: the hosted plan left a column panel behind");
+    for (const HostPanel& p : plan.panels) {
+        HostArgs a;
+        a.M = M; a.W = W; a.V = V; a.mat = w.mat; a.npad = w.npad; a.nb = w.nb; a.q = w.q;
+        a.J = p.J; a.pe = p.pe;
+        a.logdet = (double*)(w.base + w.off_logdet); a.info = (int*)(w.base + w.off_info);
+        a.njobs = p.njobs;
+        memcpy(a.job, p.job, sizeof(a.job));
+        hipLaunchKernelGGL((host_kernel<T>), dim3((unsigned)(w.q + p.nhost)), dim3(HOST_NT), 0, st, a);
+        CHECK_LAUNCH("host_kernel");
+        if (p.ne == p.pe) break;
+        // the rows below: L[R, panel] = X[R, panel] W_PP^T
+        GemmArgs g;
+        g.sA = g.sB = g.sC = w.mat; g.ldA = g.ldB = g.ldC = w.npad;
+        g.B = W; g.C = M; g.nb = w.nb; g.p0 = p.J; g.p2 = p.pe; g.q = w.q; g.t0 = 0; g.skipq = 1;
+        const int rows = w.nb - p.pe;
+        if (p.J == 0) {        // panel 0 sits in M: in place, block column by block column from the right
+            g.A = M; g.p3 = 0;
+            for (int jt = p.pe - p.J - 1; jt >= 0; --jt) {
+                g.p1 = jt;
+                hipLaunchKernelGGL((tile_gemm<T, OP_PSOLVE, 64, 4>), dim3((unsigned)rows * w.q), dim3(256), 0, st, g);
+                CHECK_LAUNCH("tile_gemm");
+            }
+        } else {
+            g.A = V; g.p1 = 0; g.p3 = p.pe - p.J;
+            hipLaunchKernelGGL((tile_gemm<T, OP_PSOLVE, 64, 4>), dim3((unsigned)rows * g.p3 * w.q), dim3(256), 0, st, g);
+            CHECK_LAUNCH("tile_gemm");
+        }
+        // the next panel's columns receive this panel: diagonal block back into M, the rows below it into V
+        GemmArgs u;
+        u.sA = u.sB = u.sC = w.mat; u.ldA = u.ldB = u.ldC = w.npad;
+        u.A = M; u.B = M; u.C = M; u.nb = w.nb; u.p0 = p.J; u.p1 = p.pe; u.p2 = p.pe; u.p3 = p.ne;
+        u.C2 = V; u.r_c2 = p.ne;
+        const int rc = launch_gemm<T, OP_SYRK>(st, u, trapezoid_tiles(w.nb, p.pe, p.ne), w.q);
+        if (rc) return rc;
+    }
+    return 0;
+}
+
 // Two-level right-looking Cholesky.  Outer panels of `ob` 64-blocks: inside a panel every 64-column step is ONE launch
 // (chain_step_kernel) that only touches the panel's block column and the rest of the panel; the trailing matrix is read
 // and written once per outer panel with K = 64 ob.  The trailing update of panel J is split by columns into one wide
@@ -2643,6 +2900,13 @@ int do_potrf(hipStream_t st, const Ws& w, const lcgp_sched& sc, bool stats_zeroe
         CHECK_LAUNCH("zero_stats");
     }
     const int dtype = sizeof(T) == 4 ? LCGP_F32 : LCGP_F64;
+    {
+        const lcgp_sched& scx = plan_host ? ((const PlanHeader*)plan_host)->sched : sc;
+        if (scx.hosted && lcgp_fill::HostPlanner::applicable(w.nb)) {
+            if (inverse_done) *inverse_done = 0;
+            return do_potrf_hosted<T>(st, w, scx);
+        }
+    }
     const lcgp_fill::Launch* launches = nullptr;
     int nlaunch = 0;
     std::vector<lcgp_fill::Launch> local;
