@@ -19,12 +19,7 @@ $(LIB): $(SRC) $(HDR) $(SCHED)
 tests/native/test_kernels: tests/native/test_kernels.cpp $(LIB) $(HDR)
 	$(HIPCC) $(CXXFLAGS) -o $@ tests/native/test_kernels.cpp -Llcgp_amd -llcgp_hip -Wl,-rpath,'$$ORIGIN/../../lcgp_amd'
 
-# tool build: the persistent launch stamps every task (tools/dag_trace.py); never the library the package loads
-trace: lcgp_amd/liblcgp_hip_trace.so
-lcgp_amd/liblcgp_hip_trace.so: $(SRC) $(HDR) $(SCHED)
-	$(HIPCC) $(CXXFLAGS) -fPIC -shared -DLCGP_DAG_TRACE '-DLCGP_SRC_HASH="LCGP_SRC_HASH=$(HASH)"' -o $@ $(SRC)
-
 clean:
 	rm -f $(LIB) tests/native/test_kernels
 
-.PHONY: all clean trace
+.PHONY: all clean

@@ -82,24 +82,6 @@ typedef struct lcgp_sched {
     int progressive_lauum;  /* with the progressive inverse: A^-1 = W^T W is accumulated behind the chain as well when the matrix
                                has at most this many 64-blocks per side (48); beyond, only L^-1 is, and A^-1 takes the one
                                launch of lcgp_lauum after the factorisation (0 = always that) */
-    int dag;                /* with a plan (lcgp_plan_build): 1 = the factorisation runs as ONE persistent launch whose tasks wait
-                               for each other through per-(segment, component) counters in the workspace, 0 = launch by launch;
-                               2 = the persistent launch with its own task order: every trailing update cut into the block
-                               columns of the next panel (near) and the rest (far), the far part in chunks that alternate
-                               with the next panel's chain (no inverse behind the chain in this order) */
-    int dag_spin_limit;     /* polls of one wait inside that launch before it gives up: the failure word is set, every later
-                               wait returns at once, the launch drains and every component reports info = -1
-                               (0 = 2,000,000 polls, about two seconds; tests set 1 to see the failure path) */
-    int dag_flags;          /* protocol variants of the persistent launch, for measurement and diagnosis (0 = the product):
-                               1 = a task always waits and acquires (no "this workgroup has already seen these dependencies"),
-                               2 = an agent-scope release fence (buffer_wbl2) in front of every publication,
-                               4 = system-scope instead of agent-scope acquire,
-                               8 = plain result stores and a release fence instead of write-through stores,
-                               16 = the next task is taken after the publication instead of before the drain */
-    int fill_wide;          /* launch-by-launch plans: 1 = the filler tiles of the trailing update's far columns and of the
-                               rank-256 updates of the progressive inverse are 128x128 (the shape of the wide tile kernel, on
-                               the four waves of a chain launch) instead of 128x64; fill_leaf / fill_step keep counting
-                               128x64 tiles, such a tile takes two of them (0 with `dag`) */
     int hosted;             /* 1 = hosted panels: ONE launch per outer panel of 256 columns in which one workgroup per component
                                factors and inverts the panel's whole diagonal block while all other workgroups run deferred
                                trailing updates (256x128 tiles, long K), followed by the panel solve of the rows below and the
@@ -133,7 +115,7 @@ int lcgp_kernel_build(void* stream, int dtype, int n, int d, int p, int q_local,
  * half_logdet (q_local doubles) and info (q_local ints) are written on the device (either may be NULL). */
 int lcgp_potrf_logdet(void* stream, int dtype, int n, int d, int p, int q_local, void* workspace,
                       double* half_logdet, int* info, const lcgp_sched* sched /*host or NULL*/,
-                      const void* plan_host /*or NULL*/, const void* plan_dev /*or NULL*/);
+                      const void* plan /*host, or NULL*/);
 
 /* K4: A_k^-1 (lower tiles) from the factor left by lcgp_potrf_logdet.  Replaces the dense
  * U diag(.) U^T products of lcgp.py:654 / 705-715 and cholesky_solve with identity (lcgp.py:785). */
@@ -165,21 +147,20 @@ int lcgp_fetch_vector(void* stream, int dtype, int n, int d, int p, int q_local,
 int lcgp_nll_grad(void* stream, int dtype, int n, int d, int p, int q_local,
                   const void* x, const void* Y, const void* sr,
                   const double* theta, void* workspace, double* out, const lcgp_sched* sched,
-                  const void* plan_host /*or NULL*/, const void* plan_dev /*or NULL*/);
+                  const void* plan /*host, or NULL*/);
 
 /* The launch plan of the factorisation, computed ONCE by the caller instead of in every evaluation (it depends on
  * dtype, n, q_local, the schedule and on whether the inverse follows -- with_inverse = 1 for lcgp_nll_grad, 0 for
  * lcgp_potrf_logdet -- and on nothing else).  The plan is a position-independent block of `bytes` bytes in HOST memory
- * owned by the caller; the caller also keeps a copy of the same bytes in DEVICE memory (any copy it likes) and passes
- * both pointers to lcgp_nll_grad / lcgp_potrf_logdet, whose `sched` argument is then ignored (the plan carries the
- * schedule it was built for).  plan_host = NULL: the plan is computed per call as before.  The library still keeps no
+ * owned by the caller, passed to lcgp_nll_grad / lcgp_potrf_logdet, whose `sched` argument is then ignored (the plan
+ * carries the schedule it was built for).  plan = NULL: the plan is computed per call.  The library still keeps no
  * state.  Replaces nothing in the reference: it is the cost of ~120 kernel launches the reference never had.
- * lcgp_plan_info: launches of the launch-by-launch form, segments / tasks of the persistent form (0 when that form is
- * not available for this plan), and what the plan leaves behind the factorisation (0 = L, 1 = and L^-1, 2 = and A^-1). */
+ * lcgp_plan_info: launches of the launch-by-launch part, hosted panels behind it, and what the plan leaves behind the
+ * factorisation (0 = L, 1 = and L^-1, 2 = and A^-1). */
 int lcgp_plan_bytes(int dtype, int n, int q_local, int with_inverse, const lcgp_sched* sched, size_t* bytes /*host out*/);
 int lcgp_plan_build(int dtype, int n, int q_local, int with_inverse, const lcgp_sched* sched,
                     void* plan /*host out*/, size_t bytes);
-int lcgp_plan_info(const void* plan /*host*/, int* nlaunch, int* nseg, int* ntasks, int* inverse_done);
+int lcgp_plan_info(const void* plan /*host*/, int* nlaunch, int* npanel, int* inverse_done);
 
 /* Assembles this rank's share of the vector the ranks all-reduce (in the reference the sum over
  * k of lcgp.py:650-661 and the gradient tape's accumulation), on the device, in a fixed summation order:
@@ -200,11 +181,13 @@ int lcgp_pack_partial(void* stream, int d, int p, int q_local, int q_total, cons
  * using L_k^-1 and z_k left in the workspace by the last lcgp_nll_grad call with the same theta.
  * `same`: 0 = x0 is not the training set; s >= 1 = row i of x0 IS training input i + s - 1 (x0 is the training set or a
  * contiguous chunk of it starting at row s - 1), so the nugget term goes to that entry (covmat.py:46-51).
- * scratch: lcgp_predict_scratch_bytes(dtype, n, q_local, n0) bytes. */
+ * scratch: lcgp_predict_scratch_bytes(dtype, n, q_local, n0) bytes.
+ * out_stride: elements between the rows of ghat / gvar (0 = n0): a caller that predicts a long batch in chunks passes
+ * the chunk's offset into its (q_local x total) arrays and the total as stride, so no per-chunk temporaries are needed. */
 int lcgp_predict(void* stream, int dtype, int n, int d, int p, int q_local,
                  const void* x, const void* sr, const double* theta, const void* workspace,
                  int n0, const void* x0, int same, void* scratch,
-                 double* ghat /*q_local x n0*/, double* gvar /*q_local x n0*/);
+                 double* ghat /*q_local rows of n0*/, double* gvar /*q_local rows of n0*/, int out_stride);
 
 #ifdef __cplusplus
 }

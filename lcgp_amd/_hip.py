@@ -25,7 +25,6 @@ class Sched(C.Structure):
     _fields_ = [("outer_blocks", C.c_int), ("syrk_small_tiles", C.c_int), ("trtri_small_tiles", C.c_int),
                 ("lauum_small_tiles", C.c_int), ("trtri_level_small", C.c_int), ("fill_leaf", C.c_int),
                 ("fill_step", C.c_int), ("leaf_in_wide", C.c_int), ("progressive_tiles", C.c_int), ("progressive_far", C.c_int), ("progressive_lauum", C.c_int),
-                ("dag", C.c_int), ("dag_spin_limit", C.c_int), ("dag_flags", C.c_int), ("fill_wide", C.c_int),
                 ("hosted", C.c_int), ("hosted_defer", C.c_int)]
 
 
@@ -44,18 +43,18 @@ SIGNATURES = {
     "lcgp_predict_scratch_bytes": (_i, [_i, _i, _i, _i, C.POINTER(C.c_size_t)]),
     "lcgp_matern32": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, C.POINTER(_d), _d, _d, _i, _vp]),
     "lcgp_kernel_build": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
-    "lcgp_potrf_logdet": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _sp, _vp, _vp]),
+    "lcgp_potrf_logdet": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _sp, _vp]),
     "lcgp_potri": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _sp]),
     "lcgp_trtri": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _sp]),
     "lcgp_lauum": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _sp]),
     "lcgp_fetch_matrix": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _i, _i, _vp]),
     "lcgp_fetch_vector": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _i, _i, _vp]),
-    "lcgp_nll_grad": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _sp, _vp, _vp]),
+    "lcgp_nll_grad": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _sp, _vp]),
     "lcgp_plan_bytes": (_i, [_i, _i, _i, _i, _sp, C.POINTER(C.c_size_t)]),
     "lcgp_plan_build": (_i, [_i, _i, _i, _i, _sp, _vp, C.c_size_t]),
-    "lcgp_plan_info": (_i, [_vp, C.POINTER(_i), C.POINTER(_i), C.POINTER(_i), C.POINTER(_i)]),
+    "lcgp_plan_info": (_i, [_vp, C.POINTER(_i), C.POINTER(_i), C.POINTER(_i)]),
     "lcgp_pack_partial": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
-    "lcgp_predict": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp, _i, _vp, _vp, _vp]),
+    "lcgp_predict": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp, _i, _vp, _vp, _vp, _i]),
 }
 
 _lib = None

@@ -46,9 +46,6 @@ struct FillJob {
     int t0;              // first tile
     int R0, R1, j0, j1;
     int kb0, kb1;
-    int wide;            // SYRK / CUPD: 1 = 128 x 128 output tiles -- the columns go in PAIRS (j, j + 1), j even (j0, j1, kb0
-                         // even), same enumeration over the pairs; such a tile is twice the work of a 128 x 64 one at half the
-                         // operand traffic per flop and runs at the rate of the 128-tile kernel
 };
 
 struct FillSet {
@@ -63,11 +60,6 @@ struct FillSet {
 inline long syrk_tiles(int R1, int j0, int j1) {
     long n = 0;
     for (int j = j0; j < j1; ++j) n += R1 - (j >> 1);
-    return n;
-}
-inline long syrk_tiles_wide(int R1, int j0, int j1) {             // column pairs (j0, j1 even)
-    long n = 0;
-    for (int j = j0; j < j1; j += 2) n += R1 - (j >> 1);
     return n;
 }
 inline long dupd_tiles(int R1) { return (long)R1 * (R1 + 1); }     // rows [0, R1)
@@ -140,8 +132,7 @@ class FillQueue {
     int take(long cap_blocks, bool allow_big, int urgent_row, FillSet& fs, bool with_dupd = true) {
         fs.njobs = 0;
         fs.nblk = 0;
-        // (the capacity counts 128 x 64 tiles: a wide tile takes two units)
-        auto cost = [&](const QJob& jb) { return (long)q * (jb.j.wide ? 2 : 1); };
+        auto cost = [&](const QJob&) { return (long)q; };
         auto emit = [&](QJob& jb, long n) {
             if (n <= 0 || fs.njobs >= NJ) return;
             FillJob& o = fs.job[fs.njobs++];
@@ -284,25 +275,15 @@ struct PlanParams {
     bool far_rides;          // the far columns of a trailing update ride on the next panel's chain (else: one wide launch)
     bool with_dupd = true;   // progressive: A^-1 = W^T W is accumulated behind the chain too (else only L^-1 is; the caller
                              // then forms A^-1 in one launch after the factorisation)
-    bool interleaved = false; // order for the persistent launch (Planner::run_interleaved): near / far trailing updates,
-                              // the far part cut into chunks that alternate with the next panel's chain
-    bool with_trtri = false;  // interleaved: the triangular inverse W = L^-1 (level-parallel products) is part of the same
-                              // sequence -- its early levels fill the chain-bound end of the factorisation
-    int trtri_all_small = 0;  // ... every level on 64 x 64 tiles (small problems); else only the first
-    int tri_fill_from = 256;  // ... they start to ride when a chain step's share of the far update drops below this many blocks
-    bool psolve = true;       // ... and the rows below the chain rows are solved per panel with the panel's 256 x 256 inverse
-    bool fill_wide = false;   // launch-by-launch plan: the far columns of the trailing update and the rank-(64 ob) updates of the
-                              // progressive inverse ride as 128 x 128 tiles (FillJob::wide; needs an even ob)
+    int stop_block = -1;     // >= 0: only the panels in front of this block column are planned (0: none), the last of them with
+                             // its WHOLE trailing update as one wide launch (hosted panels follow: lcgp_hip.hip, HostPlanner)
 };
 
 enum LaunchKind {
     L_LEAF = 1,              // diagonal block J (+ filler)
     L_STEP = 2,              // chain step of block column c (+ filler)
     L_TRAIL = 3,             // wide trailing update of panel [J, pe) on the block columns [c_lo, c_hi)
-    L_FILL = 4,              // filler jobs on their own
-    L_TRI = 5,               // one step (T = L21 W11 or W21 = -W22 T) of one level of the triangular inverse, a range of pairs
-    L_PSOLVE = 6             // panel solve of the rows below the chain rows: L[R, jt] = sum_{kt <= jt} A[R, kt] W_PP[jt, kt]^T for the
-                             // 128-column tile jt (= c_lo) of the panel [J, pe) and the 128-row tiles from block row r_lo on
+    L_FILL = 4               // filler jobs on their own
 };
 
 struct Launch {
@@ -311,27 +292,11 @@ struct Launch {
     int kind = 0;
     int J = 0, pe = 0, c = 0;
     int diag_end = 0, has_special = 0, n_trmm = 0, n_upd = 0;       // L_STEP
-    int trmm_r0 = 0, upd_r0 = 0;                                    // L_STEP: first block row of its n_trmm solve tiles / n_upd delayed
-                                                                    // update tiles (0 = c + 1 / c + 2: all rows below the diagonal)
     int c_lo = 0, c_hi = 0, tiles128 = 0, with_leaf = 0;            // L_TRAIL
-    int t_first = 0, t_count = 0;                                   // L_TRAIL: a sub-range of its tiles (t_count = 0: all of them)
-    int r_lo = 0, r_hi = 0;                                         // L_TRAIL: block rows [max(column, r_lo), r_hi) of every block
-                                                                    // column (r_hi = 0: down to the last row)
-    int tri_mb = 0, tri_p0 = 0, tri_np = 0, tri_w = 0;              // L_TRI: level block size (tiles), first pair, pairs, 0 = T / 1 = W
-                                                                    // (tiles128 = tile size)
     FillSet fs;                                                     // job descriptors (base pointers are set by the executor)
 };
 
 inline long rect_tiles(int nb, int c_lo, int c_hi) { return syrk_tiles(nb / 2, c_lo, c_hi); }
-// tiles of a trailing-update region: tile columns [c_lo, c_hi), in column c the tile rows [max(c, r_lo), r_hi)
-inline long region_tiles(int c_lo, int c_hi, int r_lo, int r_hi) {
-    long n = 0;
-    for (int c = c_lo; c < c_hi; ++c) {
-        const int a = c > r_lo ? c : r_lo;
-        if (r_hi > a) n += r_hi - a;
-    }
-    return n;
-}
 inline int trapezoid_tiles(int nb, int c_lo, int c_hi) { return (c_hi - c_lo) * nb - (c_lo + c_hi - 1) * (c_hi - c_lo) / 2; }
 
 class Planner {
@@ -340,186 +305,11 @@ class Planner {
     std::vector<Launch> launches;
     bool inverse_planned = false;
 
-    // Order for the persistent launch (dag_kernel takes the tasks of all segments in sequence): the trailing update of
-    // panel P is cut into its NEAR part -- the block columns of panel P + 1, all the next chain reads or writes -- and its
-    // FAR part, and the far part into chunks that alternate with the launches of the chain of panel P + 1:
-    //     ... near(P) | leaf | far(P) 1/5 | step | far(P) 2/5 | step | ... | near(P+1) | ...
-    // A chain task then never waits for far tiles (the dependencies are derived per segment from the blocks it touches),
-    // the workgroups that are not on the chain always find update tiles to run, and no update ends in a half-empty round
-    // of tiles because nothing ends at all: the next segment's tiles follow.  Executed launch by launch the list is valid
-    // too (it is what tests/test_fill_sched.py replays), only slow.
-    void run_interleaved() {
-        const int nb = pp.nb, ob = pp.ob, q = pp.q;
-        const bool t128 = (ob & 1) == 0;
-        // pending "fill" work of the previous panel: the rest of its near columns and its far columns (in chunks)
-        struct Fill { bool on; Launch l; long ntiles; long given; };
-        Fill rest = {false, Launch(), 0, 0}, far = {false, Launch(), 0, 0};
-        auto emit_chunk = [&](Fill& f, long upto) {
-            if (!f.on || upto > f.ntiles) upto = f.on ? f.ntiles : 0;
-            if (!f.on || upto <= f.given) return;
-            Launch l = f.l;
-            l.t_first = (int)f.given;
-            l.t_count = (int)(upto - f.given);
-            launches.push_back(l);
-            f.given = upto;
-        };
-        std::vector<Launch> bulk;        // bulk parts of this panel's chain steps, waiting for a slot in the order
-        // Units of the triangular inverse (one step of one level for a run of pairs), sorted by the panel that completes
-        // their rows of L, then by level: every unit comes behind the units it reads from.
-        struct Tri { Launch l; int ready; long blocks; };
-        std::vector<Tri> tri;
-        if (pp.with_trtri) {
-            for (int P = 0; P * ob < nb; ++P) {
-                for (int mb64 = 1; mb64 < nb; mb64 *= 2) {
-                    const int tm128 = (mb64 == 1 || pp.trtri_all_small || !t128) ? 0 : 1;
-                    const int u = tm128 ? 2 : 1, mb = mb64 / u, nbt = nb / u;
-                    for (int w = 0; w < 2; ++w) {
-                        int first = -1, count = 0;
-                        auto flush = [&]() {
-                            if (count == 0) return;
-                            Tri t;
-                            t.l = Launch();
-                            t.l.kind = L_TRI; t.l.tiles128 = tm128; t.l.tri_mb = mb; t.l.tri_p0 = first; t.l.tri_np = count; t.l.tri_w = w;
-                            t.l.fs.njobs = 0; t.l.fs.nblk = 0;
-                            t.ready = P;
-                            t.blocks = (long)count * mb * mb * q;
-                            tri.push_back(t);
-                            count = 0; first = -1;
-                        };
-                        for (int pr = 0; (2 * pr + 1) * mb < nbt; ++pr) {
-                            int last = (2 * pr + 2) * mb * u;            // one past the last 64-block row the pair reads
-                            if (last > nb) last = nb;
-                            const int rp = (last - 1) / ob;
-                            if (rp == P) { if (count == 0) first = pr; ++count; }
-                            else flush();
-                        }
-                        flush();
-                    }
-                }
-            }
-        }
-        // Rows below the chain rows: with 128-aligned panels and the inverse in the sequence they skip the 64-column steps
-        // altogether -- once the panel's diagonal block and ITS inverse W_PP exist (the first levels of the triangular
-        // inverse, which ride right behind the panel's chain), L[R, panel] = A[R, panel] W_PP^T is ONE product on 128 x 128
-        // tiles per 128 columns (a quarter of the arithmetic of the four solve + update steps, at the tile kernel's rate).
-        const bool use_psolve = pp.with_trtri && t128 && !pp.trtri_all_small && pp.psolve;
-        size_t tri_next = 0;
-        int panel_idx = 0;
-        auto emit_tri = [&](long budget_blocks, int done_panel) {
-            // units whose rows of L are complete (panels <= done_panel), in order, up to the budget
-            while (tri_next < tri.size() && tri[tri_next].ready <= done_panel && budget_blocks > 0) {
-                launches.push_back(tri[tri_next].l);
-                budget_blocks -= tri[tri_next].blocks;
-                ++tri_next;
-            }
-        };
-        for (int J = 0; J < nb; J += ob, ++panel_idx) {
-            const int pe = J + ob < nb ? J + ob : nb;
-            const int ne = pe + ob < nb ? pe + ob : nb;            // end of the next panel
-            const int rch = ne + ob < nb ? ne + ob : nb;           // chain rows: this panel's, the next one's and the one after
-            {
-                Launch l;
-                l.kind = L_LEAF; l.J = J; l.pe = pe;
-                l.fs.njobs = 0; l.fs.nblk = 0;
-                launches.push_back(l);
-            }
-            emit_chunk(rest, rest.ntiles);                          // (needed by the bulk rows of this panel's chain)
-            int nsteps = 0;
-            for (int c = J; c < pe && c + 1 < nb; ++c) ++nsteps;
-            int si = 0;
-            for (int c = J; c < pe && c + 1 < nb; ++c, ++si) {
-                // chain part: the rows the following diagonal blocks need; bulk part: all rows below them
-                const bool upd = c > J && c + 1 < pe;
-                Launch l;
-                l.kind = L_STEP; l.J = J; l.pe = pe; l.c = c;
-                l.diag_end = pe;
-                l.fs.njobs = 0; l.fs.nblk = 0;
-                Launch ch = l, bk = l;
-                ch.has_special = c + 1 < pe ? 1 : 0;
-                ch.trmm_r0 = c + 1; ch.n_trmm = (rch < nb ? rch : nb) - (c + 1);
-                ch.upd_r0 = c + 2; ch.n_upd = upd ? (rch < nb ? rch : nb) - (c + 2) : 0;
-                if (ch.n_upd < 0) ch.n_upd = 0;
-                bk.has_special = 0;
-                bk.trmm_r0 = rch; bk.n_trmm = use_psolve ? 0 : nb - rch;
-                bk.upd_r0 = rch; bk.n_upd = (upd && !use_psolve) ? nb - rch : 0;
-                launches.push_back(ch);
-                // fill behind the chain step: the bulk rows of the step before, a share of the far update
-                if (!bulk.empty()) { launches.push_back(bulk.back()); bulk.pop_back(); }
-                const long far_before = far.on ? far.given : 0;
-                emit_chunk(far, far.ntiles * (si + 1) / (nsteps > 0 ? nsteps : 1));
-                // the chain-bound end of the factorisation: units of the inverse whose rows of L were complete TWO panels ago
-                // (their last producers are well behind in the sequence) take the room the far update no longer fills
-                {
-                    const long far_blocks = ((far.on ? far.given : 0) - far_before) * (far.on && far.l.tiles128 ? 4 : 1) * q;
-                    if (far_blocks < pp.tri_fill_from) emit_tri(pp.tri_fill_from - far_blocks, panel_idx - 2);
-                }
-                if (bk.n_trmm > 0) bulk.push_back(bk);
-            }
-            emit_chunk(far, far.ntiles);
-            far.on = false; rest.on = false;
-            if (pe < nb) {
-                // the near update in two parts: what the next chain reads (on 64 x 64 tiles: it is on the critical path) ...
-                Launch l;
-                l.kind = L_TRAIL; l.J = J; l.pe = pe; l.c_lo = pe; l.c_hi = ne; l.tiles128 = 0; l.with_leaf = 0;
-                l.r_lo = 0; l.r_hi = rch;
-                l.t_first = 0; l.t_count = (int)region_tiles(pe, ne, 0, rch);
-                l.fs.njobs = 0; l.fs.nblk = 0;
-                launches.push_back(l);
-            }
-            while (!bulk.empty()) { launches.push_back(bulk.back()); bulk.pop_back(); }
-            if (use_psolve) {
-                // the panel's own levels of the inverse (the 64-block pairs inside it, then its 128-blocks), then the solve
-                // of the rows below, column tile by column tile from the right (a tile reads the ones to its left)
-                size_t keep = 0;
-                std::vector<Tri> later;
-                for (size_t i = tri_next; i < tri.size(); ++i) {
-                    const Launch& tl = tri[i].l;
-                    const int span = tl.tri_mb * (tl.tiles128 ? 2 : 1) * 2;        // 64-blocks a pair covers
-                    if (tri[i].ready == panel_idx && span <= ob) launches.push_back(tl);
-                    else later.push_back(tri[i]);
-                    (void)keep;
-                }
-                tri.erase(tri.begin() + tri_next, tri.end());
-                tri.insert(tri.end(), later.begin(), later.end());
-                if (rch < nb)
-                    for (int jt = (pe - J) / 2 - 1; jt >= 0; --jt) {
-                        Launch l;
-                        l.kind = L_PSOLVE; l.J = J; l.pe = pe; l.c_lo = jt; l.r_lo = rch; l.tiles128 = 1;
-                        l.fs.njobs = 0; l.fs.nblk = 0;
-                        launches.push_back(l);
-                    }
-            }
-            if (pe >= nb) break;
-            // ... and its rows below (needed by the bulk rows of the next chain), then the far columns
-            if (rch < nb) {
-                rest.on = true; rest.given = 0;
-                Launch& l = rest.l;
-                l = Launch();
-                l.kind = L_TRAIL; l.J = J; l.pe = pe; l.c_lo = pe; l.c_hi = ne; l.with_leaf = 0;
-                l.tiles128 = t128 ? 1 : 0;
-                l.r_lo = rch; l.r_hi = nb;
-                l.fs.njobs = 0; l.fs.nblk = 0;
-                rest.ntiles = t128 ? region_tiles(pe / 2, ne / 2, rch / 2, nb / 2) : region_tiles(pe, ne, rch, nb);
-            }
-            if (ne < nb) {
-                far.on = true; far.given = 0;
-                Launch& l = far.l;
-                l = Launch();
-                l.kind = L_TRAIL; l.J = J; l.pe = pe; l.c_lo = ne; l.c_hi = nb; l.with_leaf = 0;
-                l.tiles128 = t128 ? 1 : 0;
-                l.r_lo = 0; l.r_hi = nb;
-                l.fs.njobs = 0; l.fs.nblk = 0;
-                far.ntiles = t128 ? region_tiles(ne / 2, nb / 2, 0, nb / 2) : region_tiles(ne, nb, 0, nb);
-            }
-        }
-        emit_tri(1L << 60, 1 << 30);          // the rest of the inverse behind the factorisation
-    }
-
     void run() {
-        if (pp.interleaved) { run_interleaved(); return; }
         const int nb = pp.nb, ob = pp.ob, q = pp.q;
         const bool t128 = (ob & 1) == 0;
         inverse_planned = pp.progressive;
+        if (pp.stop_block == 0) return;
         bool leaf_done = false;
         // filler capacity of a panel's chain launches, with and without a diagonal-block launch of its own
         const int cap_with_leaf = pp.fill_leaf + (ob - 1) * pp.fill_step;
@@ -548,7 +338,9 @@ class Planner {
             // carries filler of its own and the 8-wave tile kernel is the faster one.
             int cf = nb;                                       // first filler column
             bool next_leaf = false;
-            if (pe < nb) {
+            const bool last_planned = pp.stop_block > 0 && pe >= pp.stop_block;      // hosted panels follow: no filler, no
+                                                                                      // diagonal block in the update launch
+            if (pe < nb && !last_planned) {
                 cf = first_filler_column(pp.far_rides ? cap_with_leaf : 0);
                 if (pp.leaf_in_wide && !wide128(cf)) {
                     const int cf3 = first_filler_column(pp.far_rides ? cap_no_leaf : 0);
@@ -571,6 +363,7 @@ class Planner {
             }
             leaf_done = next_leaf && pe < cf;
             queue_far_update(J, pe, cf);
+            if (last_planned) break;
         }
         // the tail of the progressive inverse: what the chain launches did not carry, in as few dependent launches as
         // the job dependencies allow; the remaining A^-1 updates merged into K bands
@@ -593,8 +386,6 @@ class Planner {
     int last_dupd = -1, last_cupd = -1;
     int kb_end = 0;               // end of the last panel whose inverse jobs are queued
 
-    bool wide_ok() const { return pp.fill_wide && (pp.ob & 1) == 0 && (pp.nb & 1) == 0; }
-
     // the far columns [cf, nb) of the trailing update of panel [J, pe) become the filler job with a deadline at the
     // end of the next panel's chain
     void queue_far_update(int J, int pe, int cf) {
@@ -603,8 +394,7 @@ class Planner {
         QJob jb;
         jb.j.type = FILL_SYRK;
         jb.j.R0 = 0; jb.j.R1 = pp.nb / 2; jb.j.j0 = cf; jb.j.j1 = pp.nb; jb.j.kb0 = J; jb.j.kb1 = pe;
-        jb.j.wide = wide_ok() && (cf & 1) == 0 ? 1 : 0;
-        jb.total = jb.j.wide ? syrk_tiles_wide(pp.nb / 2, cf, pp.nb) : syrk_tiles(pp.nb / 2, cf, pp.nb);
+        jb.total = syrk_tiles(pp.nb / 2, cf, pp.nb);
         jb.ready_launch = fq.launch;
         fq.syrk_job = fq.add(jb);
     }
@@ -649,8 +439,7 @@ class Planner {
             QJob jb;
             jb.j.type = FILL_CUPD;
             jb.j.R0 = pe / 2; jb.j.R1 = nb / 2; jb.j.j0 = 0; jb.j.j1 = pe; jb.j.kb0 = J; jb.j.kb1 = pe;
-            jb.j.wide = wide_ok() && (pe & 1) == 0 && (J & 1) == 0 ? 1 : 0;
-            jb.ncols = jb.j.wide ? pe / 2 : pe;
+            jb.ncols = pe;
             jb.total = (long)(jb.j.R1 - jb.j.R0) * jb.ncols;
             jb.ready_launch = now + (last_step ? 1 : 0);   // the panel's last block column of L is final after that launch
             jb.dep[0] = w_done;
@@ -720,453 +509,6 @@ class Planner {
 };
 
 // ---------------------------------------------------------------------------------------------------
-// The same plan as a task graph for ONE persistent launch (lcgp_hip.hip: dag_kernel).
-//
-// A SEGMENT is what a launch (or one filler job of a launch) is in the launch-by-launch executor: a kind, its integer
-// parameters and a number of workgroup-sized TASKS, enumerated exactly like the blocks of that launch.  All tasks of
-// the graph form one global sequence (segment after segment); the workgroups of the persistent kernel take them in that
-// order from one counter, so a task that has been taken is held by a RUNNING workgroup and everything it may wait for
-// lies before it in the sequence: the earliest unfinished task can always run, whatever number of workgroups is
-// resident (no co-residency assumption, no deadlock).
-// Dependencies are per (segment, component): a task of component k starts when the counters cnt[dep, k] of the
-// segments listed in `dep` have reached `need` (all tasks of that segment and component have finished); when it ends it
-// adds one to cnt[own segment, k].  The lists are DERIVED here from the blocks each segment reads and writes
-// (rectangles of 64x64 blocks per matrix; a conflict is an overlap with at least one writer: read-after-write,
-// write-after-write and write-after-read alike) and reduced transitively.  tests/test_fill_sched.py replays the graph
-// on numpy matrices and checks every block-level hazard against the declared lists.
-// ---------------------------------------------------------------------------------------------------
-constexpr int DAG_MAXDEP = 16;
-
-enum SegKind { S_LEAF = 1, S_STEP = 2, S_TRAIL = 3, S_FILL = 4, S_TRI = 5, S_PSOLVE = 6 };
-
-struct DagSeg {
-    int kind;
-    int t0, ntasks;          // task ids [t0, t0 + ntasks)
-    int per_comp;            // tasks per component (= what cnt[this segment, k] reaches)
-    int k_off;               // component of task b (index within the segment): b < k_off ? b : (b - k_off) % q
-    int ndeps;
-    int dep[DAG_MAXDEP];     // segment indices (all smaller than this segment's)
-    int need[DAG_MAXDEP];    // their per_comp
-    int J, pe, c, diag_end, has_special, n_trmm, n_upd;      // S_LEAF (J) / S_STEP
-    int c_lo, c_hi, tiles128, with_leaf;                     // S_TRAIL (+ J, pe)
-    int t_first, t_count;                                    // S_TRAIL: a sub-range of the update's tiles (t_count = 0: all)
-    int r_lo, r_hi;                                          // S_TRAIL: block rows [max(column, r_lo), r_hi) (r_hi = 0: all)
-    int trmm_r0, upd_r0;                                     // S_STEP: first block row of the solve / delayed-update tiles
-    int tri_mb, tri_p0, tri_np, tri_w;                       // S_TRI (+ tiles128)
-    FillJob job;                                             // S_FILL
-};
-
-enum { BUF_M = 0, BUF_W = 1, BUF_V = 2, BUF_STAT = 3 };
-
-struct Access {
-    int buf, r0, r1, c0, c1;     // blocks [r0, r1) x [c0, c1) of one component's matrix
-    bool write;
-};
-
-class DagBuilder {
- public:
-    std::vector<DagSeg> segs;
-    std::vector<std::vector<Access>> acc;     // per segment (kept for the dump / tests)
-    int ntasks = 0;
-    bool failed = false;
-
-    DagBuilder(int nb_, int q_) : nb(nb_), q(q_) {}
-
-    void build(const std::vector<Launch>& launches) {
-        for (const Launch& l : launches) {
-            if (l.kind == L_LEAF) {
-                DagSeg s = blank(S_LEAF);
-                s.J = l.J; s.pe = l.pe;
-                s.ntasks = q; s.per_comp = 1; s.k_off = q;
-                std::vector<Access> a;
-                leaf_access(a, l.J);
-                push(s, a);
-            } else if (l.kind == L_STEP) {
-                DagSeg s = blank(S_STEP);
-                s.J = l.J; s.pe = l.pe; s.c = l.c; s.diag_end = l.diag_end; s.has_special = l.has_special;
-                s.n_trmm = l.n_trmm; s.n_upd = l.n_upd;
-                s.trmm_r0 = l.trmm_r0 ? l.trmm_r0 : l.c + 1;
-                s.upd_r0 = l.upd_r0 ? l.upd_r0 : l.c + 2;
-                s.per_comp = l.n_trmm + l.n_upd;
-                s.ntasks = s.per_comp * q;
-                s.k_off = l.has_special ? q : 0;
-                std::vector<Access> a;
-                step_access(a, l);
-                if (s.ntasks > 0) push(s, a);
-            } else if (l.kind == L_TRAIL) {
-                DagSeg s = blank(S_TRAIL);
-                s.J = l.J; s.pe = l.pe; s.c_lo = l.c_lo; s.c_hi = l.c_hi; s.tiles128 = l.tiles128; s.with_leaf = l.with_leaf;
-                std::vector<Access> a;
-                int nt;
-                const int u = l.tiles128 ? 2 : 1, nbt = nb / u;
-                const int rlo = l.r_lo / u, rhi = l.r_hi ? l.r_hi / u : nbt;
-                s.r_lo = l.r_lo; s.r_hi = l.r_hi;
-                if (l.t_count > 0 || l.r_lo || l.r_hi) {
-                    // tiles [t_first, t_first + t_count) of the region (column-major over the tile columns from c_lo on, in
-                    // column c the tile rows [max(c, r_lo), r_hi)): the blocks they touch, column by column
-                    const long total = region_tiles(l.c_lo / u, l.c_hi / u, rlo, rhi);
-                    const long first = l.t_count > 0 ? l.t_first : 0;
-                    long left = l.t_count > 0 ? l.t_count : total;
-                    nt = (int)left;
-                    int c = l.c_lo / u;
-                    long t = first;
-                    auto col_tiles = [&](int cc) { const int lo = cc > rlo ? cc : rlo; return rhi > lo ? rhi - lo : 0; };
-                    while (c < l.c_hi / u && t >= col_tiles(c)) { t -= col_tiles(c); ++c; }
-                    while (left > 0 && c < l.c_hi / u) {
-                        const long in_col = col_tiles(c) - t;
-                        const long take = left < in_col ? left : in_col;
-                        const int ra = (c > rlo ? c : rlo) + (int)t, rb = ra + (int)take;
-                        a.push_back({BUF_M, ra * u, rb * u, c * u, (c + 1) * u, true});
-                        a.push_back({BUF_M, ra * u, rb * u, l.J, l.pe, false});
-                        a.push_back({BUF_M, c * u, (c + 1) * u, l.J, l.pe, false});
-                        left -= take; t = 0; ++c;
-                    }
-                    if (left > 0) { failed = true; return; }
-                    s.t_first = (int)first; s.t_count = nt;
-                } else {
-                    nt = l.tiles128 ? trapezoid_tiles(nb / 2, l.c_lo / 2, l.c_hi / 2) + (l.with_leaf ? 1 : 0)
-                                    : trapezoid_tiles(nb, l.c_lo, l.c_hi);
-                    a.push_back({BUF_M, l.c_lo, nb, l.J, l.pe, false});
-                    a.push_back({BUF_M, l.c_lo, nb, l.c_lo, l.c_hi, true});
-                    if (l.with_leaf) leaf_access(a, l.c_lo);
-                }
-                s.per_comp = nt;
-                s.ntasks = nt * q;
-                s.k_off = l.with_leaf ? q : 0;
-                push(s, a);
-            }
-            if (l.kind == L_TRI) {
-                DagSeg s = blank(S_TRI);
-                s.tiles128 = l.tiles128; s.tri_mb = l.tri_mb; s.tri_p0 = l.tri_p0; s.tri_np = l.tri_np; s.tri_w = l.tri_w;
-                s.per_comp = l.tri_np * l.tri_mb * l.tri_mb;
-                s.ntasks = s.per_comp * q; s.k_off = 0;
-                std::vector<Access> a;
-                const int u = l.tiles128 ? 2 : 1, mb = l.tri_mb * u;              // in 64-blocks
-                for (int pr = l.tri_p0; pr < l.tri_p0 + l.tri_np; ++pr) {
-                    const int C0 = 2 * pr * mb, R0 = C0 + mb;
-                    const int Re = R0 + mb < nb ? R0 + mb : nb;
-                    if (R0 >= nb) continue;
-                    if (l.tri_w == 0) {
-                        a.push_back({BUF_M, R0, Re, C0, R0, false});
-                        a.push_back({BUF_W, C0, R0, C0, R0, false});
-                        a.push_back({BUF_V, R0, Re, C0, R0, true});
-                    } else {
-                        a.push_back({BUF_W, R0, Re, R0, Re, false});
-                        a.push_back({BUF_V, R0, Re, C0, R0, false});
-                        a.push_back({BUF_W, R0, Re, C0, R0, true});
-                    }
-                }
-                push(s, a);
-            }
-            if (l.kind == L_PSOLVE) {
-                DagSeg s = blank(S_PSOLVE);
-                s.J = l.J; s.pe = l.pe; s.c_lo = l.c_lo; s.r_lo = l.r_lo; s.tiles128 = 1;
-                s.per_comp = (nb - l.r_lo) / 2;
-                s.ntasks = s.per_comp * q; s.k_off = 0;
-                std::vector<Access> a;
-                const int c0 = l.J + 2 * l.c_lo;                       // first 64-block column of the tile column
-                a.push_back({BUF_M, l.r_lo, nb, l.J, c0 + 2, false});
-                a.push_back({BUF_W, c0, c0 + 2, l.J, c0 + 2, false});
-                a.push_back({BUF_M, l.r_lo, nb, c0, c0 + 2, true});
-                if (s.ntasks > 0) push(s, a);
-            }
-            for (int i = 0; i < l.fs.njobs; ++i) {
-                const FillJob& jb = l.fs.job[i];
-                if (jb.nblk <= 0) continue;
-                DagSeg s = blank(S_FILL);
-                s.job = jb;
-                s.ntasks = jb.nblk; s.per_comp = jb.nblk / q; s.k_off = 0;
-                std::vector<Access> a;
-                job_access(a, jb);
-                push(s, a);
-            }
-        }
-        derive_deps();
-    }
-
- private:
-    int nb, q;
-
-    static DagSeg blank(int kind) {
-        DagSeg s;
-        s.kind = kind; s.t0 = 0; s.ntasks = 0; s.per_comp = 0; s.k_off = 0; s.ndeps = 0;
-        for (int i = 0; i < DAG_MAXDEP; ++i) { s.dep[i] = -1; s.need[i] = 0; }
-        s.J = s.pe = s.c = s.diag_end = s.has_special = s.n_trmm = s.n_upd = 0;
-        s.c_lo = s.c_hi = s.tiles128 = s.with_leaf = 0; s.t_first = s.t_count = 0;
-        s.r_lo = s.r_hi = s.trmm_r0 = s.upd_r0 = 0;
-        s.tri_mb = s.tri_p0 = s.tri_np = s.tri_w = 0;
-        s.job.type = FILL_NONE; s.job.nblk = 0; s.job.t0 = 0; s.job.R0 = s.job.R1 = s.job.j0 = s.job.j1 = 0;
-        s.job.kb0 = s.job.kb1 = 0;
-        return s;
-    }
-
-    void push(DagSeg& s, const std::vector<Access>& a) {
-        s.t0 = ntasks;
-        ntasks += s.ntasks;
-        segs.push_back(s);
-        acc.push_back(a);
-    }
-
-    // diagonal block j: factor in place, inverse into W (and the zero quadrant beside an even block), running statistics
-    void leaf_access(std::vector<Access>& a, int j) const {
-        a.push_back({BUF_M, j, j + 1, j, j + 1, true});
-        a.push_back({BUF_W, j, j + 1, j, j + 1, true});
-        if ((j & 1) == 0 && j + 1 < nb) a.push_back({BUF_W, j, j + 1, j + 1, j + 2, true});
-        a.push_back({BUF_STAT, 0, 1, 0, 1, true});
-    }
-
-    void step_access(std::vector<Access>& a, const Launch& l) const {
-        const int c = l.c;
-        const int t0 = l.trmm_r0 ? l.trmm_r0 : c + 1, t1 = t0 + l.n_trmm;        // rows of the solve tiles
-        const int u0 = l.upd_r0 ? l.upd_r0 : c + 2, u1 = u0 + l.n_upd;          // rows of the delayed-update tiles
-        if (l.n_trmm > 0) {
-            a.push_back({BUF_W, c, c + 1, c, c + 1, false});
-            if (c > l.J) {
-                a.push_back({BUF_M, c, c + 1, c - 1, c, false});                  // L[c, c-1]
-                a.push_back({BUF_M, t0, t1, c - 1, c, false});                    // L[r, c-1]
-            }
-            a.push_back({BUF_M, t0, t1, c, c + 1, true});                        // the block column itself
-            const int de = l.diag_end < t1 ? l.diag_end : t1;
-            for (int r = t0; r < de; ++r) a.push_back({BUF_M, r, r + 1, r, r + 1, true});
-        }
-        if (l.has_special) leaf_access(a, c + 1);
-        if (l.n_upd > 0) {
-            a.push_back({BUF_M, u0, u1, c + 1, c + 2, true});
-            if (c > l.J) {
-                a.push_back({BUF_M, u0, u1, l.J, c, false});
-                a.push_back({BUF_M, c + 1, c + 2, l.J, c, false});
-            }
-        }
-    }
-
-    // blocks touched by the tiles [t0, t0 + nblk / q) of a filler job (bounding rectangles; see the enumerations above)
-    void job_access(std::vector<Access>& a, const FillJob& jb) const {
-        const long n = jb.nblk / q;
-        const int kb0 = jb.kb0, kb1 = jb.kb1;
-        if (jb.type == FILL_SYRK) {
-            // column-major over j, rows R in [j / 2, R1): per column touched one rectangle
-            long t = jb.t0;
-            int j = jb.j0;
-            while (t >= jb.R1 - (j >> 1)) { t -= jb.R1 - (j >> 1); ++j; }
-            long left = n;
-            while (left > 0 && j < jb.j1) {
-                const long in_col = jb.R1 - (j >> 1) - t;
-                const long take = left < in_col ? left : in_col;
-                const int Ra = (j >> 1) + (int)t, Rb = Ra + (int)take;
-                a.push_back({BUF_M, 2 * Ra, 2 * Rb, j, j + 1, true});
-                a.push_back({BUF_M, 2 * Ra, 2 * Rb, kb0, kb1, false});
-                a.push_back({BUF_M, j, j + 1, kb0, kb1, false});
-                left -= take; t = 0; ++j;
-            }
-        } else if (jb.type == FILL_BROW || jb.type == FILL_CUPD) {
-            const int nc = jb.j1 - jb.j0;
-            long t = jb.t0, left = n;
-            while (left > 0) {
-                const int R = jb.R0 + (int)(t / nc), ja = jb.j0 + (int)(t % nc);
-                const long in_row = nc - (t % nc);
-                const long take = left < in_row ? left : in_row;
-                const int jz = ja + (int)take;
-                if (jb.type == FILL_BROW) {
-                    const int ke = kb1 < 2 * R + 2 ? kb1 : 2 * R + 2;
-                    a.push_back({BUF_W, 2 * R, 2 * R + 2, ja, jz, true});
-                    a.push_back({BUF_W, 2 * R, 2 * R + 2, kb0, ke, false});
-                    a.push_back({BUF_V, kb0, ke, ja, jz, false});
-                } else {
-                    a.push_back({BUF_V, 2 * R, 2 * R + 2, ja, jz, true});
-                    a.push_back({BUF_M, 2 * R, 2 * R + 2, kb0, kb1, false});
-                    a.push_back({BUF_W, kb0, kb1, ja, jz, false});
-                }
-                left -= take; t += take;
-            }
-        } else if (jb.type == FILL_DUPD) {
-            long t = jb.t0, left = n;
-            while (left > 0) {
-                int R = 0;
-                while ((long)(R + 1) * (R + 2) <= t) ++R;
-                const int ja = (int)(t - (long)R * (R + 1));
-                const long in_row = 2 * R + 2 - ja;
-                const long take = left < in_row ? left : in_row;
-                const int jz = ja + (int)take;
-                const int ks = 2 * R >= kb0 ? 2 * R : kb0;
-                a.push_back({BUF_V, 2 * R, 2 * R + 2, ja, jz, true});
-                a.push_back({BUF_W, ks, kb1, 2 * R, 2 * R + 2, false});
-                a.push_back({BUF_W, ks, kb1, ja, jz, false});
-                left -= take; t += take;
-            }
-        } else {
-            // TRI_T / TRI_W: one level of the block inverse, pairs [j0, j0 + R1) of block size mb = R0 (the whole level:
-            // a job of a level is small)
-            const int mb = jb.R0;
-            for (int pr = jb.j0; pr < jb.j0 + jb.R1; ++pr) {
-                const int C0 = 2 * pr * mb, R0 = C0 + mb;
-                const int Re = R0 + mb < nb ? R0 + mb : nb;
-                if (R0 >= nb) continue;
-                if (jb.type == FILL_TRI_T) {
-                    a.push_back({BUF_M, R0, Re, C0, R0, false});
-                    a.push_back({BUF_W, C0, R0, C0, R0, false});
-                    a.push_back({BUF_V, R0, Re, C0, R0, true});
-                } else {
-                    a.push_back({BUF_W, R0, Re, R0, Re, false});
-                    a.push_back({BUF_V, R0, Re, C0, R0, false});
-                    a.push_back({BUF_W, R0, Re, C0, R0, true});
-                }
-            }
-        }
-    }
-
-    static bool overlap(const Access& x, const Access& y) {
-        return x.buf == y.buf && (x.write || y.write) && x.r0 < y.r1 && y.r0 < x.r1 && x.c0 < y.c1 && y.c0 < x.c1;
-    }
-    bool conflict(int s, int t) const {
-        for (const Access& x : acc[s])
-            for (const Access& y : acc[t])
-                if (overlap(x, y)) return true;
-        return false;
-    }
-
-    void derive_deps() {
-        const int ns = (int)segs.size();
-        const int nw = (ns + 63) / 64;
-        std::vector<unsigned long long> clo((size_t)ns * nw, 0ull);      // transitive closure of the kept dependencies
-        for (int s = 0; s < ns; ++s) {
-            unsigned long long* cs = &clo[(size_t)s * nw];
-            for (int t = s - 1; t >= 0; --t) {
-                if ((cs[t >> 6] >> (t & 63)) & 1ull) continue;            // already implied
-                if (!conflict(t, s)) continue;
-                DagSeg& sg = segs[s];
-                if (sg.ndeps >= DAG_MAXDEP) { failed = true; return; }
-                sg.dep[sg.ndeps] = t;
-                sg.need[sg.ndeps] = segs[t].per_comp;
-                ++sg.ndeps;
-                cs[t >> 6] |= 1ull << (t & 63);
-                const unsigned long long* ct = &clo[(size_t)t * nw];
-                for (int w = 0; w < nw; ++w) cs[w] |= ct[w];
-            }
-        }
-    }
-};
-
-// ---------------------------------------------------------------------------------------------------
-// The ORDER of the one task sequence (dag_kernel takes the tasks in sequence order; a task that is not ready blocks the
-// workgroup that took it, so the order decides how much of the chip waits).  The graph is scheduled on the host the way
-// the GPU will run it: a list schedule on `slots` workgroup slots with estimated task durations, always giving a free slot
-// the ready segment with the longest path to the end of the graph (the chain of diagonal blocks first, update tiles and
-// the inverse as filling).  The order in which the simulation STARTS tasks is the sequence: runs (segment, first task,
-// count).  A run only follows runs of everything its segment depends on, because a segment becomes ready in the
-// simulation only after all tasks of its dependencies have started AND ended -- so the in-order argument of dag_kernel
-// (the earliest unfinished task can always run) holds for any durations, right or wrong; wrong estimates cost waiting,
-// never correctness.  Counters stay per (segment, component): the runs of a segment share them.
-// ---------------------------------------------------------------------------------------------------
-struct DagRun {
-    int seg;       // segment
-    int b0, n;     // its tasks [b0, b0 + n)
-    int t0;        // position of the run's first task in the sequence
-};
-
-inline double seg_task_us(const DagSeg& s, int ob) {
-    switch (s.kind) {
-        case S_LEAF: return 17.0;
-        case S_STEP: return s.has_special ? 22.0 : 12.0;
-        case S_TRAIL: return (s.tiles128 ? 62.0 : 21.0) * (s.pe - s.J) / 4.0 + (s.with_leaf ? 10.0 : 0.0);
-        case S_PSOLVE: return 35.0 * (s.c_lo + 1);
-        case S_TRI: return s.tiles128 ? 10.0 + 35.0 * (s.tri_mb + 1) * 0.5 : 4.0 + 3.0 * (s.tri_mb + 1) * 0.5;
-        default: return 25.0 * (s.job.kb1 - s.job.kb0 > 0 ? (s.job.kb1 - s.job.kb0) / 4.0 : 1.0);
-    }
-    (void)ob;
-}
-
-class DagScheduler {
- public:
-    std::vector<DagRun> runs;
-
-    // segs: in any order consistent with their dependency lists (DagBuilder's).  slots: resident workgroups.
-    void run(const std::vector<DagSeg>& segs, int slots, int ob) {
-        const int ns = (int)segs.size();
-        std::vector<double> dur(ns), bl(ns, 0.0);
-        std::vector<std::vector<int>> succ(ns);
-        std::vector<int> ndep(ns, 0);
-        for (int i = 0; i < ns; ++i) {
-            dur[i] = seg_task_us(segs[i], ob);
-            ndep[i] = segs[i].ndeps;
-            for (int d = 0; d < segs[i].ndeps; ++d) succ[segs[i].dep[d]].push_back(i);
-        }
-        // bottom level: the longest chain of task durations from the segment to the end (a segment with more tasks than
-        // slots counts its rounds)
-        for (int i = ns - 1; i >= 0; --i) {
-            double m = 0.0;
-            for (int j : succ[i]) if (bl[j] > m) m = bl[j];
-            const double rounds = (double)((segs[i].ntasks + slots - 1) / slots);
-            bl[i] = m + dur[i] * (rounds > 1.0 ? rounds : 1.0);
-        }
-        std::vector<int> next(ns, 0), done(ns, 0);
-        std::vector<int> ready;                       // indices of ready segments with tasks left
-        for (int i = 0; i < ns; ++i) if (ndep[i] == 0) ready.push_back(i);
-        struct Ev { double t; int seg, n; };
-        std::vector<Ev> heap;                         // min-heap on t
-        auto hpush = [&](Ev e) {
-            heap.push_back(e);
-            size_t i = heap.size() - 1;
-            while (i > 0 && heap[(i - 1) / 2].t > heap[i].t) { std::swap(heap[(i - 1) / 2], heap[i]); i = (i - 1) / 2; }
-        };
-        auto hpop = [&]() {
-            Ev top = heap[0];
-            heap[0] = heap.back();
-            heap.pop_back();
-            size_t i = 0;
-            for (;;) {
-                size_t l = 2 * i + 1, r = l + 1, m = i;
-                if (l < heap.size() && heap[l].t < heap[m].t) m = l;
-                if (r < heap.size() && heap[r].t < heap[m].t) m = r;
-                if (m == i) break;
-                std::swap(heap[m], heap[i]);
-                i = m;
-            }
-            return top;
-        };
-        double now = 0.0;
-        int free_slots = slots, t0 = 0;
-        long left = 0;
-        for (int i = 0; i < ns; ++i) left += segs[i].ntasks;
-        while (left > 0) {
-            // hand the free slots to the ready segments, longest remaining path first
-            while (free_slots > 0 && !ready.empty()) {
-                int bi = 0;
-                for (int i = 1; i < (int)ready.size(); ++i)
-                    if (bl[ready[i]] > bl[ready[bi]] || (bl[ready[i]] == bl[ready[bi]] && ready[i] < ready[bi])) bi = i;
-                const int s = ready[bi];
-                int m = segs[s].ntasks - next[s];
-                if (m > free_slots) m = free_slots;
-                if (!runs.empty() && runs.back().seg == s && runs.back().b0 + runs.back().n == next[s]) runs.back().n += m;
-                else runs.push_back({s, next[s], m, t0});
-                t0 += m;
-                hpush({now + dur[s], s, m});
-                next[s] += m;
-                free_slots -= m;
-                left -= m;
-                if (next[s] >= segs[s].ntasks) { ready[bi] = ready.back(); ready.pop_back(); }
-            }
-            if (left <= 0) break;
-            if (heap.empty()) { failed = true; return; }       // (a cycle or a dangling dependency: cannot happen for a DagBuilder graph)
-            // advance to the next completion (and everything that ends at the same time)
-            const double t = heap[0].t;
-            now = t;
-            while (!heap.empty() && heap[0].t <= t) {
-                const Ev e = hpop();
-                free_slots += e.n;
-                done[e.seg] += e.n;
-                if (done[e.seg] >= segs[e.seg].ntasks)
-                    for (int j : succ[e.seg])
-                        if (--ndep[j] == 0) ready.push_back(j);
-            }
-        }
-        makespan_us = now;
-        while (!heap.empty()) { const Ev e = hpop(); if (e.t > makespan_us) makespan_us = e.t; }
-    }
-    bool failed = false;
-    double makespan_us = 0.0;
-};
-
-// ---------------------------------------------------------------------------------------------------
 // Hosted panels (lcgp_hip.hip: host_kernel).  Per outer panel P of `ob` = 4 block columns three launches:
 //   A(P)  q chain workgroups factor the panel's whole diagonal block (and invert it), all other workgroups run DEFERRED
 //         trailing updates: jobs (column panels, K range) -- 256 x 128 tiles of  M[R, c] -= sum_{k0 <= k < k1} L[R, k] L[c, k]^T;
@@ -1204,16 +546,17 @@ struct HostPanel {
 
 class HostPlanner {
  public:
-    // nb: 64-blocks per side (a multiple of ob = 4), q components, defer >= 1
-    HostPlanner(int nb_, int q_, int defer_) : nb(nb_), q(q_), defer(defer_ < 1 ? 1 : defer_) {}
+    // nb: 64-blocks per side (a multiple of ob = 4), q components, defer >= 1, first hosted panel p0 (the panels in front of
+    // it have been factored AND applied to everything behind them: right-looking up to there)
+    HostPlanner(int nb_, int q_, int defer_, int p0_ = 0) : nb(nb_), q(q_), defer(defer_ < 1 ? 1 : defer_), p0(p0_) {}
     std::vector<HostPanel> panels;
     bool failed = false;
     static bool applicable(int nb) { return nb >= 8 && nb % 4 == 0; }
 
     void run() {
         const int ob = 4, np = nb / ob;
-        std::vector<int> applied(np, 0);          // panels [0, applied[c]) have been applied to column panel c
-        for (int P = 0; P < np; ++P) {
+        std::vector<int> applied(np, p0);         // panels [0, applied[c]) have been applied to column panel c
+        for (int P = p0; P < np; ++P) {
             HostPanel hp;
             hp.J = P * ob; hp.pe = hp.J + ob; hp.ne = P + 1 < np ? hp.pe + ob : hp.pe;
             for (int c = P + 1; c < np; ++c) {
@@ -1248,7 +591,7 @@ class HostPlanner {
     }
 
  private:
-    int nb, q, defer;
+    int nb, q, defer, p0;
 };
 
 }  // namespace lcgp_fill

@@ -22,7 +22,7 @@
 #include "../../include/lcgp_hip.h"
 #include "fill_sched.h"
 
-#define LCGP_VERSION 310
+#define LCGP_VERSION 400
 
 namespace {
 
@@ -56,16 +56,11 @@ struct Ws {
     size_t esz;
     size_t mat;          // elements per matrix
     char* base;
-    size_t off_M, off_W, off_V, off_b, off_z, off_part, off_cpart, off_c, off_logdet, off_info, off_dag, off_trace, total;
+    size_t off_M, off_W, off_V, off_b, off_z, off_part, off_cpart, off_c, off_logdet, off_info, total;
     int ntile_lower;
 };
 
 inline size_t align256(size_t x) { return (x + 255) & ~size_t(255); }
-
-// control words of the persistent factorisation launch (dag_kernel): 16 ints + one counter per (segment, component); the
-// bound on the segments of a plan follows from fill_sched.h (launches <= 8 nb + 16, at most 1 + NJ segments per launch)
-inline size_t dag_ctl_ints(int nb, int q) { return 16 + (size_t)(56 * nb + 112) * q; }
-constexpr int DAG_TRACE_CAP = 1 << 18;
 
 inline Ws carve(int dtype, int n, int d, int p, int q, void* base) {
     Ws w;
@@ -89,11 +84,6 @@ inline Ws carve(int dtype, int n, int d, int p, int q, void* base) {
     w.off_c = o; o = align256(o + (dtype == LCGP_F64 ? 0 : (size_t)w.npad * q * sizeof(double)));
     w.off_logdet = o; o = align256(o + (size_t)q * sizeof(double));
     w.off_info = o; o = align256(o + (size_t)q * sizeof(int));
-    w.off_dag = o; o = align256(o + dag_ctl_ints(w.nb, q) * sizeof(int));
-    w.off_trace = o;
-#ifdef LCGP_DAG_TRACE
-    o = align256(o + (size_t)DAG_TRACE_CAP * 32);       // tool build: four time stamps per task at the END of the workspace
-#endif
     w.total = o;
     return w;
 }
@@ -118,28 +108,14 @@ template <> struct Mfma<float> {
     static __device__ __forceinline__ int row(int lane, int reg) { return (lane >> 4) * 4 + reg; }
 };
 
-// Thread index of a tile body.  Opaque to the optimiser on purpose: inside the persistent kernel (dag_kernel) the bodies
-// sit in a loop, and with the plain intrinsic every lane-dependent address computation of every body is hoisted in front
-// of that loop and kept alive across it (149 spilled registers in the fp64 build).
+// Thread index of a tile body.  Opaque to the optimiser on purpose: where bodies sit in a loop (the chain workgroup of
+// host_kernel), every lane-dependent address computation of every body would otherwise be hoisted in front of that loop
+// and kept alive across it (the diagonal-block code needs the whole register file itself).
 __device__ __forceinline__ int body_tid() {
     int t = threadIdx.x;
     asm volatile("" : "+v"(t));
     __builtin_assume(t >= 0 && t < 1024);
     return t;
-}
-// Store of a result element.  WT (the persistent launch): write-through -- the element leaves for memory at once (sc1), so
-// that publishing a finished tile to other workgroups needs no write-back of the whole L2 (buffer_wbl2) behind it: every
-// storing wave drains its stores, the workgroup meets at a barrier, one lane adds to the counter (MI355X_MICROARCH.md,
-// inter-workgroup visibility: write-through payload + drained flag; the consumer side keeps its agent-scope acquire).
-template <bool WT, typename T>
-__device__ __forceinline__ void gstore(T* p, T v) {
-    if constexpr (WT) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    else *p = v;
-}
-// the same for a wave-uniform value that comes from the kernel arguments
-__device__ __forceinline__ int opaque_s(int v) {
-    asm volatile("" : "+s"(v));
-    return v;
 }
 
 __device__ __forceinline__ void tri_decode(int t, int& r, int& c) {
@@ -526,26 +502,26 @@ __device__ __forceinline__ void leaf_inverse_w(double (*w)[LEAF_LDT], const d4& 
 // The results leave for memory as they become final, on waves that would otherwise wait at the panel's barrier: L panel
 // kb-1 and row block kb-2 of the inverse during panel kb (and the zero quadrant beside W during panel 0), so that only
 // the last panel, the last two row blocks and the log-determinant are left after the chain.
-template <typename T, bool WT>
+template <typename T>
 __device__ __forceinline__ void leaf_store_l_panel(T* __restrict__ Mb, int npad, double (*lt)[LEAF_LDT], int pb, int lane) {
     const int col = pb * 16 + (lane & 15);
 #pragma unroll
     for (int m = 0; m < 16; ++m) {
         const int i = (lane >> 4) + 4 * m;
-        gstore<WT>(Mb + (size_t)i * npad + col, (T)lt[col][i]);
+        Mb[(size_t)i * npad + col] = (T)lt[col][i];
     }
 }
 
-template <typename T, bool WT>
+template <typename T>
 __device__ __forceinline__ void leaf_store_w_rows(T* __restrict__ Wb, int npad, double (*w)[LEAF_LDT], int a, int lane) {
 #pragma unroll
     for (int m = 0; m < 16; ++m) {
         const int i = a * 16 + m;
-        gstore<WT>(Wb + (size_t)i * npad + lane, (T)(lane <= i ? w[i][lane] : 0.0));
+        Wb[(size_t)i * npad + lane] = (T)(lane <= i ? w[i][lane] : 0.0);
     }
 }
 
-template <typename T, bool FROM_LDS, bool WT>
+template <typename T, bool FROM_LDS>
 __device__ __forceinline__ void leaf_factor_invert(T* __restrict__ Mb, T* __restrict__ Wb, int npad, double (*lt)[LEAF_LDT],
                                                    double (*w)[LEAF_LDT], double* scratch, double* dinv, double* pivs,
                                                    int* bad, int jb) {
@@ -605,11 +581,11 @@ __device__ __forceinline__ void leaf_factor_invert(T* __restrict__ Mb, T* __rest
         } else if (kb == 0) {
             // the 128x128 tile kernels read whole diagonal 128-blocks of W: keep the quadrant above this block zero
             if ((jb & 1) == 0)
-                for (int i = wv - 1; i < TS; i += 3) gstore<WT>(Wb + (size_t)i * npad + TS + lane, (T)0);
+                for (int i = wv - 1; i < TS; i += 3) Wb[(size_t)i * npad + TS + lane] = (T)0;
         } else if (wv == ((kb + 1) & 3)) {
-            leaf_store_l_panel<T, WT>(Mb, npad, lt, kb - 1, lane);
+            leaf_store_l_panel<T>(Mb, npad, lt, kb - 1, lane);
         } else if (kb >= 2 && wv == ((kb + 2) & 3)) {
-            leaf_store_w_rows<T, WT>(Wb, npad, w, kb - 2, lane);
+            leaf_store_w_rows<T>(Wb, npad, w, kb - 2, lane);
         }
         __syncthreads();
         if (wv > kb) {
@@ -630,13 +606,13 @@ __device__ __forceinline__ void leaf_factor_invert(T* __restrict__ Mb, T* __rest
     else tacc = leaf_inverse_t(lt, w, 3, wv, lane);
     __syncthreads();
     if (wv < 3) leaf_inverse_w(w, tacc, 3, wv, lane);
-    else leaf_store_l_panel<T, WT>(Mb, npad, lt, 3, lane);
+    else leaf_store_l_panel<T>(Mb, npad, lt, 3, lane);
     __syncthreads();
-    if (wv == 1) leaf_store_w_rows<T, WT>(Wb, npad, w, 2, lane);
-    else if (wv == 2) leaf_store_w_rows<T, WT>(Wb, npad, w, 3, lane);
+    if (wv == 1) leaf_store_w_rows<T>(Wb, npad, w, 2, lane);
+    else if (wv == 2) leaf_store_w_rows<T>(Wb, npad, w, 3, lane);
 }
 
-template <typename T, bool FROM_LDS = false, bool WT = false>
+template <typename T, bool FROM_LDS = false>
 __device__ __forceinline__ void leaf_body(unsigned char* lds, int k, T* __restrict__ M, T* __restrict__ W, size_t mat,
                                           int npad, int jb, double* __restrict__ logdet, int* __restrict__ info) {
     double (*lt)[LEAF_LDT] = (double (*)[LEAF_LDT])lds;                   // lt[col][row] = L[row][col]
@@ -652,14 +628,14 @@ __device__ __forceinline__ void leaf_body(unsigned char* lds, int k, T* __restri
     double ld_prev = 0.0;
     int info_prev = 0;
     if (tid == 0) { ld_prev = logdet[k]; info_prev = info[k]; }
-    leaf_factor_invert<T, FROM_LDS, WT>(Mb, Wb, npad, lt, w, scratch, dinv, pivs, bad, jb);
+    leaf_factor_invert<T, FROM_LDS>(Mb, Wb, npad, lt, w, scratch, dinv, pivs, bad, jb);
     if (tid < TS) {   // wave 0 (the other waves are storing the last rows): 1/2 sum log(pivot)
         double lg = 0.5 * log(pivs[tid]);
         for (int off = 32; off > 0; off >>= 1) lg += __shfl_xor(lg, off);
         if (tid == 0) {
-            gstore<WT>(logdet + k, ld_prev + lg);
+            logdet[k] = ld_prev + lg;
             const int fb = bad[0] ? bad[0] : bad[1] ? bad[1] : bad[2] ? bad[2] : bad[3];
-            if (fb && info_prev == 0) gstore<WT>(info + k, fb);
+            if (fb && info_prev == 0) info[k] = fb;
         }
     }
 }
@@ -678,7 +654,7 @@ __global__ __launch_bounds__(256, 2) void leaf_kernel(T* __restrict__ M, T* __re
 //   MK : element (m, k) at P[m * ld + k]      KM : element (m, k) at P[k * ld + m]
 // and staged in LDS as [k][m] (KT = 16 k rows per stage, double buffered through registers).
 // ---------------------------------------------------------------------------------------------------
-enum GemmOp { OP_SYRK = 1, OP_TRTRI_T = 2, OP_TRTRI_W = 3, OP_LAUUM = 4, OP_PRED_U = 5, OP_PSOLVE = 6, OP_CUPD = 7 };
+enum GemmOp { OP_SYRK = 1, OP_TRTRI_T = 2, OP_TRTRI_W = 3, OP_LAUUM = 4, OP_PRED_U = 5, OP_PSOLVE = 6 };
 enum Lay { MK = 0, KM = 1 };
 
 struct GemmArgs {
@@ -688,10 +664,9 @@ struct GemmArgs {
     int nb;                                     // number of 64-blocks
     int p0, p1, p2, p3;                         // op specific
     int q;                                      // components in this launch
-    int t0;                                     // first tile of this launch (OP_SYRK: a launch may cover a sub-range)
+    int t0;                                     // first tile of this launch (OP_SYRK)
     int skipq;                                  // OP_SYRK on 128-tiles: tile 0 leaves its top-left 64x64 quadrant alone
                                                 // (the diagonal block there is factored by the same launch, wide_leaf_kernel)
-    int r_lo = 0, r_hi = 0;                     // OP_SYRK: tile rows [max(column, r_lo), r_hi) of every tile column (r_hi = 0: to nb)
     const void* bvec = nullptr;                 // OP_LAUUM on 128-tiles: b (npad per component) and the partial buffer of
     double* part = nullptr;                     // z = A^-1 b, [component][tile][2][128]; null = no fused product
     void* C2 = nullptr; int r_c2 = 0;           // OP_SYRK: tiles of the rows >= r_c2 are STORED into this matrix instead of C
@@ -780,11 +755,11 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 //   TM = 128, NW = 8: 32x64 per wave (2x4 accumulators), 2 workgroups per CU = 4 waves per SIMD, half the
 //                     operand traffic per flop of the 64-tile
 // All tile coordinates (g.nb, g.p0..p3) are in units of TM.
-template <typename T, int OP, int TM, int NW, bool WT = false>
+template <typename T, int OP, int TM, int NW>
 __device__ __forceinline__ void gemm_body(const GemmArgs& g, const int lin /*block index within this descriptor*/,
                                           unsigned char* lds) {
     constexpr int LA = (OP == OP_LAUUM) ? KM : MK;
-    constexpr int LB = (OP == OP_TRTRI_T || OP == OP_TRTRI_W || OP == OP_LAUUM || OP == OP_CUPD) ? KM : MK;
+    constexpr int LB = (OP == OP_TRTRI_T || OP == OP_TRTRI_W || OP == OP_LAUUM) ? KM : MK;
     constexpr int NT = NW * 64;
     constexpr int LD = TM + 16;     // = 16 (mod 32): the two k rows a 32-lane group reads hit disjoint banks
     constexpr int WTM = TM / (NW / 2), WTN = TM / 2;   // per-wave sub-tile
@@ -828,10 +803,8 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, const int lin /*blo
         // M[r, c] -= sum_{kt in [p0, p1)} M[r, kt] M[c, kt]^T over the tiles c in [p2, p3), r in [c, nb)
         // (p3 == nb: the whole trailing triangle; p3 < nb: the rest of the current panel), column-major
         int t = bid + g.t0, c = g.p2;
-        const int rhi = g.r_hi ? g.r_hi : g.nb;
-        int rfirst = c > g.r_lo ? c : g.r_lo;
-        while (t >= rhi - rfirst) { t -= rhi - rfirst; ++c; rfirst = c > g.r_lo ? c : g.r_lo; }
-        const int r = rfirst + t;
+        while (t >= g.nb - c) { t -= g.nb - c; ++c; }
+        const int r = c + t;
         A0 = Ab + (size_t)r * TM * g.ldA + (size_t)g.p0 * TM; dA = TM;
         B0 = Bb + (size_t)c * TM * g.ldB + (size_t)g.p0 * TM; dB = TM;
         nkt = g.p1 - g.p0;
@@ -889,20 +862,6 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, const int lin /*blo
         B0 = Bb + (size_t)(c0 + jt) * TM * g.ldB + (size_t)c0 * TM; dB = TM;
         nkt = jt + 1;
         Ct = Cb + (size_t)R * TM * g.ldC + (size_t)(c0 + jt) * TM;
-    } else if constexpr (OP == OP_CUPD) {
-        // Rank-(panel) update of the progressive inverse (fill_sched.h: FILL_CUPD, wide form), tiles row-major over the rows
-        // R in [p2, ..) and the p3 tile columns from r_lo on:  V[R, c] (+)= sum_{kt = ks}^{p1 - 1} M[R, kt] W[kt, c],  the k tiles
-        // [p0, p1) = the panel; a column inside the panel starts at its own block row (zeros above) and is the first
-        // contribution to its tile.  (A from M, B from W, C in V.)
-        const int t = bid + g.t0;
-        const int R = g.p2 + t / g.p3, c = g.r_lo + t % g.p3;
-        const bool own = c >= g.p0;
-        const int ks = own ? c : g.p0;
-        A0 = Ab + (size_t)R * TM * g.ldA + (size_t)ks * TM; dA = TM;
-        B0 = Bb + (size_t)ks * TM * g.ldB + (size_t)c * TM; dB = (ptrdiff_t)TM * g.ldB;
-        nkt = g.p1 - ks;
-        Ct = Cb + (size_t)R * TM * g.ldC + (size_t)c * TM;
-        accumulate = !own;
     } else {
         // OP_PRED_U: U[m, r] = sum_{kt = 0}^{r} X[m, kt] W[r, kt]^T    (X = scaled cross covariance, n0pad x npad)
         const int r = g.nb - 1 - bid / g.p0, m = bid % g.p0;       // p0 = row tiles of X; longest k loops (large r) first
@@ -944,7 +903,7 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, const int lin /*blo
     // only add exact zeros: it skips the stage's fragment reads and MFMAs (one wave-uniform test per stage, nothing
     // else changes; bit-identical results: the zeros are stored zeros).  LAUUM / TRTRI_W: 24 of the 64 (wave, stage)
     // pairs of such a tile, TRTRI_T / PRED_U: 16.
-    constexpr bool HAS_TRI = OP != OP_SYRK && OP != OP_CUPD;
+    constexpr bool HAS_TRI = OP != OP_SYRK;
     const int tri_first = HAS_TRI ? (nkt - 1) * SPT : nst;
     // the wave is idle in the stages [dead_lo, dead_hi) of the k loop (two scalars per wave)
     int dead_lo = nst, dead_hi = nst;
@@ -1003,7 +962,7 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, const int lin /*blo
         // holds its C tile in the accumulators from the start, so it looks ONE stage ahead (an fp64 stage is ~1.7 us of
         // MFMA work per workgroup: enough to cover an L2/HBM round trip with two workgroups per CU); deeper would spill.
         constexpr bool F64 = sizeof(T) == 8;
-        constexpr int PF = (OP == OP_SYRK || (OP == OP_CUPD && NW == 4)) ? (F64 ? 1 : 2) : (TM == 64 ? (F64 ? 2 : 4) : 2);
+        constexpr int PF = OP == OP_SYRK ? (F64 ? 1 : 2) : (TM == 64 ? (F64 ? 2 : 4) : 2);
         T ra[PF][EPT], rb[PF][EPT];
 #pragma unroll
         for (int h = 0; h < PF; ++h) {
@@ -1044,11 +1003,11 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, const int lin /*blo
                     if (g.skipq && bid + g.t0 == 0 && row < TS && col < TS) continue;
                 }
                 if constexpr (PRELOAD_C) {
-                    gstore<WT>(dst, (T)acc[mi][ni][e]);
+                    *dst = (T)acc[mi][ni][e];
                 } else {
                     double v = alpha * (double)acc[mi][ni][e];
                     if (accumulate) v += (double)*dst;
-                    gstore<WT>(dst, (T)v);
+                    *dst = (T)v;
                 }
             }
     if constexpr (OP == OP_LAUUM && TM == 128) {
@@ -1122,7 +1081,7 @@ __global__ __launch_bounds__(NW * 64, TM == 128 ? (NW == 8 ? 4 : 2) : 4) void ti
 using lcgp_fill::FillJob;
 using lcgp_fill::FillSet;
 
-template <typename T, int LA, int LB, bool NEG, bool WT = false>
+template <typename T, int LA, int LB, bool NEG>
 __device__ __forceinline__ void rect_tile(const T* __restrict__ A0, int ldA, const T* __restrict__ B0, int ldB,
                                           T* __restrict__ Ct, int ldC, int nst, bool first, unsigned char* lds) {
     constexpr int TMR = 128, TNC = 64, NT = 256, NJ_ = TNC / 32;
@@ -1213,11 +1172,11 @@ __device__ __forceinline__ void rect_tile(const T* __restrict__ A0, int ldA, con
         for (int j = 0; j < NJ_; ++j)
 #pragma unroll
             for (int e = 0; e < 4; ++e)
-                gstore<WT>(Ct + (size_t)(wm0 + i * 16 + Mfma<T>::row(lane, e)) * ldC + wn0 + j * 16 + (lane & 15), (T)acc[i][j][e]);
+                Ct[(size_t)(wm0 + i * 16 + Mfma<T>::row(lane, e)) * ldC + wn0 + j * 16 + (lane & 15)] = (T)acc[i][j][e];
 }
 
 // One block of a filler set: block b of the launch's filler range -> (job, component, tile) -> operands (fill_sched.h).
-template <typename T, bool WT = false, bool WIDE = true /* false: the persistent launch, whose plans have no wide jobs */>
+template <typename T>
 __device__ __forceinline__ void fill_dispatch(const FillSet& fs, int b, unsigned char* lds) {
     int ji = 0;
     while (ji + 1 < fs.njobs && b >= fs.job[ji].nblk) { b -= fs.job[ji].nblk; ++ji; }
@@ -1229,10 +1188,10 @@ __device__ __forceinline__ void fill_dispatch(const FillSet& fs, int b, unsigned
         g.p0 = jb.R0; g.p1 = jb.R1; g.p2 = jb.j0; g.p3 = 0; g.q = fs.q; g.t0 = 0; g.skipq = 1;
         if (jb.type == lcgp_fill::FILL_TRI_T) {
             g.A = fs.M; g.B = fs.W; g.C = fs.V;
-            gemm_body<T, OP_TRTRI_T, 64, 4, WT>(g, b + jb.t0 * fs.q, lds);       // (a job may be split over launches)
+            gemm_body<T, OP_TRTRI_T, 64, 4>(g, b + jb.t0 * fs.q, lds);       // (a job may be split over launches)
         } else {
             g.A = fs.W; g.B = fs.V; g.C = fs.W;
-            gemm_body<T, OP_TRTRI_W, 64, 4, WT>(g, b + jb.t0 * fs.q, lds);
+            gemm_body<T, OP_TRTRI_W, 64, 4>(g, b + jb.t0 * fs.q, lds);
         }
         return;
     }
@@ -1242,33 +1201,19 @@ __device__ __forceinline__ void fill_dispatch(const FillSet& fs, int b, unsigned
     T* W = (T*)fs.W + (size_t)k * fs.mat;
     T* V = (T*)fs.V + (size_t)k * fs.mat;
     const int kb0 = jb.kb0, kb1 = jb.kb1;
-    if (WIDE && jb.wide) {
-        // 128 x 128 tiles (column pairs): the body of the wide tile kernel on the four waves of this launch, same enumeration
-        GemmArgs g;
-        g.sA = g.sB = g.sC = fs.mat; g.ldA = g.ldB = g.ldC = ld; g.nb = fs.nb / 2;
-        g.q = fs.q; g.t0 = jb.t0; g.skipq = 0;
-        if (jb.type == lcgp_fill::FILL_SYRK) {
-            g.A = fs.M; g.B = fs.M; g.C = fs.M;
-            g.p0 = kb0 / 2; g.p1 = kb1 / 2; g.p2 = jb.j0 / 2; g.p3 = jb.j1 / 2; g.r_lo = 0; g.r_hi = jb.R1;
-            gemm_body<T, OP_SYRK, 128, 4, WT>(g, b, lds);
-        } else {      // FILL_CUPD
-            g.A = fs.M; g.B = fs.W; g.C = fs.V;
-            g.p0 = kb0 / 2; g.p1 = kb1 / 2; g.p2 = jb.R0; g.p3 = (jb.j1 - jb.j0) / 2; g.r_lo = jb.j0 / 2; g.r_hi = 0;
-            gemm_body<T, OP_CUPD, 128, 4, WT>(g, b, lds);
-        }
-    } else if (jb.type == lcgp_fill::FILL_SYRK) {
+    if (jb.type == lcgp_fill::FILL_SYRK) {
         // M[R, j] -= sum_k M[R, k] M[j, k]^T over the block columns [kb0, kb1)
         int j = jb.j0;
         while (t >= jb.R1 - (j >> 1)) { t -= jb.R1 - (j >> 1); ++j; }
         const int R = (j >> 1) + t;
-        rect_tile<T, MK, MK, true, WT>(M + (size_t)R * 128 * ld + (size_t)kb0 * TS, ld, M + (size_t)j * TS * ld + (size_t)kb0 * TS, ld,
+        rect_tile<T, MK, MK, true>(M + (size_t)R * 128 * ld + (size_t)kb0 * TS, ld, M + (size_t)j * TS * ld + (size_t)kb0 * TS, ld,
                                    M + (size_t)R * 128 * ld + (size_t)j * TS, ld, (kb1 - kb0) * (TS / KT), false, lds);
     } else if (jb.type == lcgp_fill::FILL_BROW) {
         // W[R, j] = -W[R, kb0 .. ] V[kb0 .., j]: row block R of the panel's block inverse (lower triangular: k < 2R + 2)
         const int nc = jb.j1 - jb.j0;
         const int R = jb.R0 + t / nc, j = jb.j0 + t % nc;
         const int ke = kb1 < 2 * R + 2 ? kb1 : 2 * R + 2;
-        rect_tile<T, MK, KM, true, WT>(W + (size_t)R * 128 * ld + (size_t)kb0 * TS, ld, V + (size_t)kb0 * TS * ld + (size_t)j * TS, ld,
+        rect_tile<T, MK, KM, true>(W + (size_t)R * 128 * ld + (size_t)kb0 * TS, ld, V + (size_t)kb0 * TS * ld + (size_t)j * TS, ld,
                                    W + (size_t)R * 128 * ld + (size_t)j * TS, ld, (ke - kb0) * (TS / KT), true, lds);
     } else if (jb.type == lcgp_fill::FILL_CUPD) {
         // V[R, j] (+)= M[R, kb0 ..] W[kb0 .., j]; a column inside the panel starts at its own 128-aligned block row (zeros
@@ -1277,7 +1222,7 @@ __device__ __forceinline__ void fill_dispatch(const FillSet& fs, int b, unsigned
         const int R = jb.R0 + t / nc, j = jb.j0 + t % nc;
         const bool own = j >= kb0;
         const int ks = kb0 + (own ? ((j - kb0) & ~1) : 0);
-        rect_tile<T, MK, KM, false, WT>(M + (size_t)R * 128 * ld + (size_t)ks * TS, ld, W + (size_t)ks * TS * ld + (size_t)j * TS, ld,
+        rect_tile<T, MK, KM, false>(M + (size_t)R * 128 * ld + (size_t)ks * TS, ld, W + (size_t)ks * TS * ld + (size_t)j * TS, ld,
                                     V + (size_t)R * 128 * ld + (size_t)j * TS, ld, (kb1 - ks) * (TS / KT), own, lds);
     } else {
         // FILL_DUPD: V[R, j] (+)= W[kb0 .., R]^T W[kb0 .., j]; a row block inside (or below) the K range starts at its own
@@ -1288,12 +1233,12 @@ __device__ __forceinline__ void fill_dispatch(const FillSet& fs, int b, unsigned
         const int j = t - R * (R + 1);
         const bool own = 2 * R >= kb0;
         const int ks = own ? 2 * R : kb0;
-        rect_tile<T, KM, KM, false, WT>(W + (size_t)ks * TS * ld + (size_t)R * 128, ld, W + (size_t)ks * TS * ld + (size_t)j * TS, ld,
+        rect_tile<T, KM, KM, false>(W + (size_t)ks * TS * ld + (size_t)R * 128, ld, W + (size_t)ks * TS * ld + (size_t)j * TS, ld,
                                     V + (size_t)R * 128 * ld + (size_t)j * TS, ld, (kb1 - ks) * (TS / KT), own, lds);
     }
 }
 
-constexpr int FILL_LDS_BYTES = 2 * KT * (128 + 16 + 128 + 16) * 8;      // (the 128 x 128 filler tile)
+constexpr int FILL_LDS_BYTES = 2 * KT * (128 + 16 + 64 + 16) * 8;
 
 // filler jobs on their own (what the chain launches could not carry, and the tail of the progressive inverse)
 template <typename T>
@@ -1369,7 +1314,6 @@ struct Tile64 {          // 64x64 tile on 256 threads: wave (wm, wn) owns a 32x3
 #pragma unroll
                 for (int e = 0; e < 4; ++e) acc[i][j][e] = 0;
     }
-    template <bool WT>
     static __device__ __forceinline__ void store(const acc_t (&acc)[2][2], T* Ct, int ld, int lane, int wm0, int wn0) {
 #pragma unroll
         for (int i = 0; i < 2; ++i)
@@ -1377,7 +1321,7 @@ struct Tile64 {          // 64x64 tile on 256 threads: wave (wm, wn) owns a 32x3
             for (int j = 0; j < 2; ++j)
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
-                    gstore<WT>(Ct + (size_t)(wm0 + i * 16 + Mfma<T>::row(lane, e)) * ld + wn0 + j * 16 + (lane & 15), (T)acc[i][j][e]);
+                    Ct[(size_t)(wm0 + i * 16 + Mfma<T>::row(lane, e)) * ld + wn0 + j * 16 + (lane & 15)] = (T)acc[i][j][e];
     }
     // One 64x64 operand (element (m, k) at P[m * ld + k]) into registers: all four K stages at once = one memory latency
     static __device__ __forceinline__ void fetch(T (&p)[SPT][EPT], const T* P, int ld, int tid) {
@@ -1489,7 +1433,7 @@ struct Tile64 {          // 64x64 tile on 256 threads: wave (wm, wn) owns a 32x3
     }
 };
 
-template <typename T, bool WT = false, bool WIDE = true>
+template <typename T>
 __device__ __forceinline__ void chain_step_body(const StepArgs& a, int b, unsigned char* lds) {
     typedef Tile64<T> TL;
     const int tid = body_tid(), lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1499,7 +1443,7 @@ __device__ __forceinline__ void chain_step_body(const StepArgs& a, int b, unsign
     const int nspecial = a.has_special * a.q;
     int t = -1, k = 0;
     if (b < nspecial) { t = 0; k = b; }
-    else if (b < nspecial + a.fs.nblk) { fill_dispatch<T, WT, WIDE>(a.fs, b - nspecial, lds); return; }
+    else if (b < nspecial + a.fs.nblk) { fill_dispatch<T>(a.fs, b - nspecial, lds); return; }
     else {
         b -= nspecial + a.fs.nblk;
         if (b < (a.n_trmm - a.has_special) * a.q) { k = b % a.q; t = b / a.q + a.has_special; }
@@ -1529,7 +1473,7 @@ __device__ __forceinline__ void chain_step_body(const StepArgs& a, int b, unsign
         TL::to_operand(acc, F, lane, wm0, wn0);
         TL::zero(acc);
         TL::template mma_a_lds<false>(acc, F, pw, Bst, tid, lane, wm0, wn0);
-        TL::template store<WT>(acc, Ct, ld, lane, wm0, wn0);         // L[r, c]
+        TL::store(acc, Ct, ld, lane, wm0, wn0);         // L[r, c]
         if (r < a.diag_end) {
             T* Dt = Mk + (size_t)r * TS * ld + (size_t)r * TS;
             typename TL::acc_t dacc[2][2];
@@ -1551,9 +1495,9 @@ __device__ __forceinline__ void chain_step_body(const StepArgs& a, int b, unsign
                         for (int e = 0; e < 4; ++e)
                             blk[wm0 + i * 16 + Mfma<T>::row(lane, e)][wn0 + j * 16 + (lane & 15)] = (double)dacc[i][j][e];
                 __syncthreads();
-                leaf_body<T, true, WT>(lds, k, (T*)a.M, (T*)a.W, a.mat, a.npad, c + 1, a.logdet, a.info);
+                leaf_body<T, true>(lds, k, (T*)a.M, (T*)a.W, a.mat, a.npad, c + 1, a.logdet, a.info);
             } else {
-                TL::template store<WT>(dacc, Dt, ld, lane, wm0, wn0);
+                TL::store(dacc, Dt, ld, lane, wm0, wn0);
             }
         }
         return;
@@ -1589,7 +1533,7 @@ __device__ __forceinline__ void chain_step_body(const StepArgs& a, int b, unsign
                 TL::template mma_regs<true>(acc, pa[1], pb[1], (T*)lds, tid, lane, wm0, wn0);
             }
         }
-        TL::template store<WT>(acc, Ct, ld, lane, wm0, wn0);
+        TL::store(acc, Ct, ld, lane, wm0, wn0);
     }
 }
 
@@ -1761,7 +1705,7 @@ __device__ __forceinline__ void chain_panel_body(unsigned char* lds, int k, cons
             TL::to_operand(acc, F, lane, wm0, wn0);
             TL::zero(acc);
             TL::template mma_a_lds<false>(acc, F, pw, Bst, tid, lane, wm0, wn0);
-            TL::template store<false>(acc, Ct, ld, lane, wm0, wn0);         // L[r, c]
+            TL::store(acc, Ct, ld, lane, wm0, wn0);         // L[r, c]
             T* Dt = Mk + (size_t)r * TS * ld + (size_t)r * TS;
             typename TL::acc_t dacc[2][2];
             TL::load(dacc, Dt, ld, lane, wm0, wn0);
@@ -1769,7 +1713,7 @@ __device__ __forceinline__ void chain_panel_body(unsigned char* lds, int k, cons
             TL::to_operand(acc, F, lane, wm0, wn0);
             __syncthreads();
             TL::template mma_ab_lds<true>(dacc, F, lane, wm0, wn0);
-            TL::template store<false>(dacc, Dt, ld, lane, wm0, wn0);
+            TL::store(dacc, Dt, ld, lane, wm0, wn0);
             __syncthreads();               // F is free; the stores are visible to the workgroup
         }
     }
@@ -1813,223 +1757,6 @@ __global__ __launch_bounds__(HOST_NT, 2) void host_kernel(HostArgs a) {
         return;
     }
     host_tile_body<T>(a, blockIdx.x - a.q, lds);
-}
-
-// ---------------------------------------------------------------------------------------------------
-// The factorisation as ONE persistent launch with dependencies inside it (fill_sched.h: DagBuilder).
-//
-// The launch-by-launch executor orders everything by kernel boundaries: all components move in lock step, a trailing
-// update ends in a partially filled round of tiles, and a chain launch lasts as long as its slowest workgroup.  Here the
-// same work items (the blocks of those launches, same bodies, same arithmetic) form one global task sequence; the
-// workgroups take the tasks in sequence order from one counter and a task waits only for what it reads or overwrites:
-//   * per (segment, component) a counter of finished tasks in the caller-owned workspace (zeroed by a memset node in
-//     front of the launch; the library still has no state);
-//   * a task of component k polls the counters of its segment's dependencies (<= 16, one lane each, relaxed agent-scope
-//     loads with s_sleep; BOUNDED: on expiry the failure word is set, every later wait returns at once, the launch
-//     drains and the components report info = -1), then ONE agent-scope acquire (buffer_inv sc1) and a workgroup
-//     barrier, then plain loads;
-//   * at its end every wave drains its stores (s_waitcnt vmcnt(0)), the workgroup meets at a barrier, and one lane
-//     publishes: agent-scope release (buffer_wbl2 sc1), s_waitcnt vmcnt(0) written as asm (ROCm 7.2 can drop the
-//     fence's own wait), then the relaxed atomic add on the counter  (MI355X_MICROARCH.md, inter-workgroup visibility).
-// Progress does not depend on how many workgroups are resident: a task that has been taken is held by a running
-// workgroup and only waits for tasks before it in the sequence, so the earliest unfinished task can always run.
-// ---------------------------------------------------------------------------------------------------
-constexpr int DAG_CTL = 16;       // ints in front of the counters: [0] next task, [1] failure word
-using lcgp_fill::DagSeg;
-
-struct DagArgs {
-    void* M; void* W; void* V; size_t mat; int npad, nb, q;
-    double* logdet; int* info;
-    const DagSeg* segs; int nseg; int ntasks;
-    const lcgp_fill::DagRun* runs; int nruns;       // the order of the sequence: runs of (segment, first task, count)
-    int* ctl;
-    unsigned spin_limit;
-    int flags;          // lcgp_sched.dag_flags
-#ifdef LCGP_DAG_TRACE
-    unsigned long long* trace;      // tool build only (make trace): per task [taken, ready, body done, published | segment | XCC]
-    int trace_cap;
-#endif
-};
-
-__device__ __forceinline__ int dag_load(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-
-template <typename T, bool WT>
-__global__ __launch_bounds__(256, 2) void dag_kernel(DagArgs a) {
-    constexpr int WIDE_LDS = 4 * KT * (128 + 16) * (int)sizeof(T);
-    __shared__ __align__(16) unsigned char lds[WIDE_LDS > LEAF_LDS_BYTES ? WIDE_LDS : LEAF_LDS_BYTES];
-    __shared__ int sh_task;
-    const int tid = threadIdx.x;
-    const DagSeg* __restrict__ segs = a.segs;
-    const lcgp_fill::DagRun* __restrict__ runs = a.runs;
-    int* cnt = a.ctl + DAG_CTL;
-    int run = 0, memo_seg = -1, memo_k = -1;
-    if (tid == 0) sh_task = __hip_atomic_fetch_add(&a.ctl[0], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    for (;;) {
-        // The task id was written to LDS by lane 0 at the END of the previous iteration.  The wait for that write is
-        // written out: hipcc (ROCm 7.2) emits this loop-header barrier as a bare s_barrier -- its waitcnt pass loses the
-        // pending ds_write across the back edge -- and the other waves then read the PREVIOUS task id now and then
-        // (two halves of a workgroup on different tasks; found on the GPU).
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __syncthreads();
-        const int t = __builtin_amdgcn_readfirstlane(sh_task);
-        if (t >= a.ntasks) break;
-#ifdef LCGP_DAG_TRACE
-        unsigned long long tr0 = 0, tr1 = 0, tr2 = 0;
-        if (tid == 0) tr0 = __builtin_amdgcn_s_memrealtime();
-#endif
-        while (t >= runs[run].t0 + runs[run].n) ++run;
-        const int seg = runs[run].seg;
-        const DagSeg& sg = segs[seg];
-        const int b = runs[run].b0 + (t - runs[run].t0);
-        const int k = b < sg.k_off ? b : (b - sg.k_off) % a.q;
-        if (seg != memo_seg || k != memo_k || (a.flags & 1)) {
-            // (a workgroup that has already waited for this segment and component has seen everything they depend on)
-            if (tid < sg.ndeps) {
-                const int* c = cnt + (size_t)sg.dep[tid] * a.q + k;
-                const int need = sg.need[tid];
-                // poll with a back-off: hundreds of workgroups may hold tasks far ahead of the chain, and their polls are
-                // memory traffic the chain's own (latency-bound) loads queue behind; a task of the chain itself keeps polling fast
-                const bool urgent = sg.kind == lcgp_fill::S_LEAF || (sg.kind == lcgp_fill::S_STEP && sg.has_special) ||
-                                    (sg.kind == lcgp_fill::S_TRAIL && !sg.tiles128 && sg.r_hi != 0);
-                unsigned it = 0;
-                while (dag_load(c) < need) {
-                    if (urgent || it < 4) __builtin_amdgcn_s_sleep(2);
-                    else if (it < 32) __builtin_amdgcn_s_sleep(16);
-                    else __builtin_amdgcn_s_sleep(64);
-                    ++it;
-                    if (it > a.spin_limit || ((it & 255u) == 0 && dag_load(&a.ctl[1]) != 0)) {
-                        __hip_atomic_store(&a.ctl[1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        break;
-                    }
-                }
-            }
-            if ((a.flags & 32) && seg > 0 && tid < a.q) {
-                // diagnosis: every segment waits for ALL tasks of the segment before it (kernel boundaries in all but name)
-                const int* c = cnt + (size_t)(seg - 1) * a.q + tid;
-                const int need = segs[seg - 1].per_comp;
-                unsigned it = 0;
-                while (dag_load(c) < need) {
-                    __builtin_amdgcn_s_sleep(4);
-                    if (++it > a.spin_limit) { __hip_atomic_store(&a.ctl[1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
-                }
-            }
-            if (a.flags & 32) __syncthreads();
-            if (tid < 64) {      // the polling lanes are lanes of wave 0: its lane 0 fences after all of them have matched
-                if (tid == 0) {
-                    if (a.flags & 4) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
-                    else __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                }
-            }
-            __syncthreads();
-            memo_seg = seg;
-            memo_k = k;
-        }
-#ifdef LCGP_DAG_TRACE
-        if (tid == 0) tr1 = __builtin_amdgcn_s_memrealtime();
-#endif
-        T* M = (T*)a.M;
-        T* W = (T*)a.W;
-        // (opaque copies: what the bodies derive from these would otherwise be computed once in front of the loop for all
-        // bodies together and held in registers across it)
-        const int npad = opaque_s(a.npad), nbk = opaque_s(a.nb), q = opaque_s(a.q);
-        const size_t mat = (size_t)npad * npad;
-        if (sg.kind == lcgp_fill::S_LEAF) {
-            leaf_body<T, false, WT>(lds, k, M, W, mat, npad, sg.J, a.logdet, a.info);
-        } else if (sg.kind == lcgp_fill::S_STEP) {
-            StepArgs sa;
-            sa.M = a.M; sa.W = a.W; sa.mat = mat; sa.npad = npad; sa.nb = nbk;
-            sa.c = sg.c; sa.J = sg.J; sa.pe = sg.pe; sa.diag_end = sg.diag_end; sa.q = q;
-            sa.has_special = sg.has_special; sa.n_trmm = sg.n_trmm; sa.n_upd = sg.n_upd;
-            sa.trmm_r0 = sg.trmm_r0; sa.upd_r0 = sg.upd_r0;
-            sa.logdet = a.logdet; sa.info = a.info;
-            sa.fs.njobs = 0; sa.fs.nblk = 0;
-            chain_step_body<T, WT, false>(sa, b, lds);
-            __builtin_amdgcn_s_setprio(0);
-        } else if (sg.kind == lcgp_fill::S_TRAIL) {
-            if (sg.with_leaf && b < q) {
-                leaf_body<T, false, WT>(lds, b, M, W, mat, npad, sg.c_lo, a.logdet, a.info);
-            } else {
-                GemmArgs g;
-                g.sA = g.sB = g.sC = mat; g.ldA = g.ldB = g.ldC = npad;
-                g.A = a.M; g.B = a.M; g.C = a.M;
-                g.q = q;
-                const int lin = b - (sg.with_leaf ? q : 0);
-                if (sg.tiles128) {
-                    g.r_lo = sg.r_lo / 2; g.r_hi = sg.r_hi / 2;
-                    g.nb = nbk / 2; g.p0 = sg.J / 2; g.p1 = sg.pe / 2; g.p2 = sg.c_lo / 2; g.p3 = sg.c_hi / 2;
-                    g.t0 = sg.t_first; g.skipq = sg.with_leaf;
-                    gemm_body<T, OP_SYRK, 128, 4, WT>(g, lin, lds);
-                } else {
-                    g.r_lo = sg.r_lo; g.r_hi = sg.r_hi;
-                    g.nb = nbk; g.p0 = sg.J; g.p1 = sg.pe; g.p2 = sg.c_lo; g.p3 = sg.c_hi;
-                    g.t0 = sg.t_first + (sg.with_leaf ? 1 : 0); g.skipq = 0;
-                    gemm_body<T, OP_SYRK, 64, 4, WT>(g, lin, lds);
-                }
-            }
-        } else if (sg.kind == lcgp_fill::S_PSOLVE) {
-            GemmArgs g;
-            g.sA = g.sB = g.sC = mat; g.ldA = g.ldB = g.ldC = npad;
-            g.A = a.M; g.B = a.W; g.C = a.M;
-            g.q = q; g.t0 = 0; g.skipq = 1; g.nb = npad / 128;
-            g.p0 = sg.J / 2; g.p1 = sg.c_lo; g.p2 = sg.r_lo / 2; g.p3 = 0;
-            gemm_body<T, OP_PSOLVE, 128, 4, WT>(g, b, lds);
-        } else if (sg.kind == lcgp_fill::S_TRI) {
-            // one step of one level of W = L^-1 for a run of pairs (do_trtri's launches, cut by the planner)
-            GemmArgs g;
-            g.sA = g.sB = g.sC = mat; g.ldA = g.ldB = g.ldC = npad;
-            g.q = q; g.t0 = 0; g.skipq = 1;          // (skipq: no grid-shaped re-enumeration of the tiles here)
-            g.p0 = sg.tri_mb; g.p1 = sg.tri_np; g.p2 = sg.tri_p0; g.p3 = 0;
-            if (sg.tri_w == 0) { g.A = a.M; g.B = a.W; g.C = a.V; }
-            else { g.A = a.W; g.B = a.V; g.C = a.W; }
-            if (sg.tiles128) {
-                g.nb = npad / 128;
-                if (sg.tri_w == 0) gemm_body<T, OP_TRTRI_T, 128, 4, WT>(g, b, lds);
-                else gemm_body<T, OP_TRTRI_W, 128, 4, WT>(g, b, lds);
-            } else {
-                g.nb = nbk;
-                if (sg.tri_w == 0) gemm_body<T, OP_TRTRI_T, 64, 4, WT>(g, b, lds);
-                else gemm_body<T, OP_TRTRI_W, 64, 4, WT>(g, b, lds);
-            }
-        } else {
-            FillSet fs;
-            fs.M = a.M; fs.W = a.W; fs.V = a.V; fs.mat = mat; fs.npad = npad; fs.nb = nbk; fs.q = q;
-            fs.njobs = 1; fs.nblk = sg.job.nblk;
-            fs.job[0] = sg.job;
-            fill_dispatch<T, WT, false>(fs, b, lds);
-        }
-        // Every store of a body is write-through (gstore<true>): once every wave has drained its stores and the workgroup
-        // has met, the results are in memory and one lane publishes them.  The next task is requested BEFORE the drain, so
-        // that the round trip of that atomic overlaps it (the task is then held for the few microseconds of the drain
-        // only -- taking it earlier would park a chain task behind a long update tile).
-#ifdef LCGP_DAG_TRACE
-        if (tid == 0) tr2 = __builtin_amdgcn_s_memrealtime();
-#endif
-        int nxt = 0;
-        if (tid == 0 && !(a.flags & 16)) nxt = __hip_atomic_fetch_add(&a.ctl[0], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (tid == 0) {
-            if (!WT || (a.flags & 2)) {
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            }
-            __hip_atomic_fetch_add(cnt + (size_t)seg * a.q + k, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (a.flags & 16) nxt = __hip_atomic_fetch_add(&a.ctl[0], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            sh_task = nxt;
-#ifdef LCGP_DAG_TRACE
-            if (a.trace && t < a.trace_cap) {
-                unsigned long long* tr = a.trace + (size_t)t * 4;
-                unsigned xcc;
-                asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-                tr[0] = tr0; tr[1] = tr1; tr[2] = tr2;
-                tr[3] = (__builtin_amdgcn_s_memrealtime() & ((1ull << 44) - 1)) | ((unsigned long long)(xcc & 15) << 60) | ((unsigned long long)seg << 44);
-            }
-#endif
-        }
-    }
-    if (dag_load(&a.ctl[1]) != 0)
-        for (int k = tid; k < a.q; k += 256) a.info[k] = -1;
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -2560,7 +2287,7 @@ __global__ void fetch_kernel(const T* __restrict__ src, int npad, int n, T* __re
 template <typename T>
 __global__ __launch_bounds__(64) void pred_reduce_kernel(const T* __restrict__ X, const T* __restrict__ U, size_t slab, int ld,
                                                          int n, const T* __restrict__ z, int npad,
-                                                         const double* __restrict__ theta, int tw, int d, int n0,
+                                                         const double* __restrict__ theta, int tw, int d, int ldo,
                                                          double* __restrict__ ghat, double* __restrict__ gvar) {
     const int m = blockIdx.x, k = blockIdx.y, lane = threadIdx.x;
     const double* th = theta + (size_t)k * tw;
@@ -2575,7 +2302,7 @@ __global__ __launch_bounds__(64) void pred_reduce_kernel(const T* __restrict__ X
         s2 += u * u;
     }
     for (int off = 32; off > 0; off >>= 1) { s1 += __shfl_xor(s1, off); s2 += __shfl_xor(s2, off); }
-    if (lane == 0) { ghat[(size_t)k * n0 + m] = s1; gvar[(size_t)k * n0 + m] = scale - D * s2; }
+    if (lane == 0) { ghat[(size_t)k * ldo + m] = s1; gvar[(size_t)k * ldo + m] = scale - D * s2; }
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -2642,12 +2369,6 @@ inline lcgp_sched default_sched() {
     s.progressive_lauum = 48;      // ... and A^-1 = W^T W accumulated behind the chain as well up to this many 64-blocks per side
                                    // (n = 2048: 1.12 -> 0.98 ms; at n = 4096 its tail is one ragged launch of long K loops
                                    // that loses to the one-launch W^T W: 2.54 vs 2.43 ms)
-    s.dag = 0;                     // 1 = with a plan (lcgp_plan_build) the factorisation runs as ONE persistent launch with
-                                   // dependencies inside it (dag_kernel) instead of launch by launch; 2 = the same with the
-                                   // trailing updates cut into near / far parts that alternate with the next panel's chain
-    s.dag_spin_limit = 0;          // polls of one wait in that launch before it gives up (0 = 2,000,000, about two seconds)
-    s.dag_flags = 0;               // protocol variants of that launch (measurement / diagnosis; see the header)
-    s.fill_wide = 0;               // 128x128 filler tiles (far columns of the trailing update, rank-256 updates of the inverse)
     s.hosted = 0;                  // 1 = hosted panels (host_kernel): one launch per outer panel whose chain workgroups share it
                                    // with deferred trailing updates
     s.hosted_defer = 2;            // ... a column panel receives the finished panels in groups of this many
@@ -2658,8 +2379,7 @@ inline int check_sched(const lcgp_sched& s) {
     if (s.outer_blocks < 0 || s.outer_blocks > 64) return bad("sched.outer_blocks must be in [0, 64]");
     if (s.syrk_small_tiles < 0 || s.trtri_small_tiles < 0 || s.lauum_small_tiles < 0 || s.trtri_level_small < 0 ||
         s.fill_leaf < 0 || s.fill_step < 0 || s.leaf_in_wide < 0 || s.progressive_tiles < 0 || s.progressive_lauum < 0 ||
-        s.dag < 0 || s.dag > 2 || s.dag_spin_limit < 0 || s.fill_wide < 0 || s.fill_wide > 1 || s.hosted < 0 || s.hosted > 1 ||
-        s.hosted_defer < 1 || s.hosted_defer > 16)
+        s.hosted < 0 || s.hosted > 1 || s.hosted_defer < 1 || s.hosted_defer > 16)
         return bad("sched fields must be >= 0");
     return 0;
 }
@@ -2677,8 +2397,7 @@ int launch_fill(hipStream_t st, const FillSet& fs) {
 
 // trailing update with the panel [J, pe) of the tile columns [c_lo, c_hi) (64-block units, all rows below)
 template <typename T>
-int potrf_trailing(hipStream_t st, const Ws& w, int J, int pe, int c_lo, int c_hi, bool tiles128, bool with_leaf,
-                   int t_first = 0, int t_count = 0, int r_lo = 0, int r_hi = 0) {
+int potrf_trailing(hipStream_t st, const Ws& w, int J, int pe, int c_lo, int c_hi, bool tiles128, bool with_leaf) {
     if (c_lo >= c_hi) return 0;
     T* M = (T*)(w.base + w.off_M);
     GemmArgs g;
@@ -2688,13 +2407,7 @@ int potrf_trailing(hipStream_t st, const Ws& w, int J, int pe, int c_lo, int c_h
     // plan decides); a launch with few tiles is bounded by the duration of one tile, which is 4x shorter on 64x64 tiles
     if (tiles128) {
         g.nb = w.nb / 2; g.p0 = J / 2; g.p1 = pe / 2; g.p2 = c_lo / 2; g.p3 = c_hi / 2;
-        const int nt = t_count > 0 ? t_count : trapezoid_tiles(w.nb / 2, c_lo / 2, c_hi / 2);
-        if (t_count > 0) {       // a sub-range of the update's tiles (the interleaved order of the persistent launch)
-            g.q = w.q; g.t0 = t_first; g.skipq = 0; g.r_lo = r_lo / 2; g.r_hi = r_hi / 2;
-            hipLaunchKernelGGL((tile_gemm<T, OP_SYRK, 128, 8>), dim3((unsigned)nt * w.q), dim3(512), 0, st, g);
-            CHECK_LAUNCH("tile_gemm");
-            return 0;
-        }
+        const int nt = trapezoid_tiles(w.nb / 2, c_lo / 2, c_hi / 2);
         if (with_leaf) {
             g.q = w.q; g.t0 = 0; g.skipq = 1;
             hipLaunchKernelGGL((wide_leaf_kernel<T, 128>), dim3((unsigned)(nt + 1) * w.q), dim3(256), 0, st, g, M,
@@ -2706,13 +2419,7 @@ int potrf_trailing(hipStream_t st, const Ws& w, int J, int pe, int c_lo, int c_h
         return launch_gemm<T, OP_SYRK, 128>(st, g, nt, w.q);
     }
     g.nb = w.nb; g.p0 = J; g.p1 = pe; g.p2 = c_lo; g.p3 = c_hi;
-    const int nt = t_count > 0 ? t_count : trapezoid_tiles(w.nb, c_lo, c_hi);
-    if (t_count > 0) {
-        g.q = w.q; g.t0 = t_first; g.skipq = 0; g.r_lo = r_lo; g.r_hi = r_hi;
-        hipLaunchKernelGGL((tile_gemm<T, OP_SYRK, 64, 4>), dim3((unsigned)nt * w.q), dim3(256), 0, st, g);
-        CHECK_LAUNCH("tile_gemm");
-        return 0;
-    }
+    const int nt = trapezoid_tiles(w.nb, c_lo, c_hi);
     if (with_leaf) {
         // tile 0 = the diagonal block itself: it belongs to the special workgroups (the chain steps of the panel have
         // already applied the panel to it)
@@ -2727,21 +2434,20 @@ int potrf_trailing(hipStream_t st, const Ws& w, int J, int pe, int c_lo, int c_h
 }
 
 // ---- the plan of a factorisation as a caller-owned, position-independent block of bytes (lcgp_plan_build) ----
-// header | Launch[nlaunch] (the launch-by-launch executor) | DagSeg[nseg] (the persistent launch; this part is what the
-// kernel reads, from the caller's DEVICE copy of the same bytes).  It depends on (dtype, n, q_local, with_inverse, sched)
-// only, so a caller builds it once and passes it with every evaluation: no planning in the evaluation loop.
+// header | Launch[nlaunch] (the launch-by-launch part) | HostPanel[npanel] (the hosted panels behind it, if any).  It
+// depends on (dtype, n, q_local, with_inverse, sched) only, so a caller builds it once and passes it with every evaluation:
+// no planning in the evaluation loop.
 constexpr unsigned PLAN_MAGIC = 0x4c43504cu;
 struct PlanHeader {
     unsigned magic;
     int version;
     int dtype, n, nb, q, with_inverse;
-    int nlaunch, nseg, ntasks;
+    int nlaunch, npanel;
+    int host_from;             // first block column of the hosted panels (nb: none)
     int inverse_done;          // what the plan leaves behind the factorisation: 0 = L, 1 = and L^-1, 2 = and A^-1
     int num_cu;
     lcgp_sched sched;
-    int nruns;
-    double sim_us;             // the list schedule's estimate of the persistent launch (fill_sched.h: DagScheduler), microseconds
-    size_t off_launch, off_seg, off_run, bytes;
+    size_t off_launch, off_panel, bytes;
 };
 
 inline lcgp_fill::PlanParams plan_params(int dtype, int nb, int q, bool with_inverse, const lcgp_sched& sc, int* inverse_done) {
@@ -2750,42 +2456,48 @@ inline lcgp_fill::PlanParams plan_params(int dtype, int nb, int q, bool with_inv
     pp.ob = sc.outer_blocks < 1 ? (dtype == LCGP_F32 ? 8 : 4) : sc.outer_blocks;
     pp.syrk_small_tiles = sc.syrk_small_tiles; pp.fill_leaf = sc.fill_leaf; pp.fill_step = sc.fill_step;
     pp.leaf_in_wide = sc.leaf_in_wide;
-    pp.interleaved = sc.dag == 2;
-    pp.fill_wide = sc.fill_wide != 0 && sc.dag == 0;
-    pp.with_trtri = pp.interleaved && with_inverse && !(sc.dag_flags & 256);      // (256: the factorisation alone in the persistent launch)
-    {
-        const int nb2 = nb / 2;
-        pp.trtri_all_small = (long long)q * (nb2 * (nb2 + 1) / 2) < sc.trtri_small_tiles ? 1 : 0;
-    }
     bool prog = false;
-    if (!pp.interleaved && with_inverse && sc.progressive_tiles > 0 && pp.ob >= 2 && (pp.ob & (pp.ob - 1)) == 0) {
+    if (with_inverse && sc.progressive_tiles > 0 && pp.ob >= 2 && (pp.ob & (pp.ob - 1)) == 0) {
         const int nb2 = nb / 2;
         prog = (long long)q * (nb2 * (nb2 + 1) / 2) <= sc.progressive_tiles;
     }
     pp.progressive = prog;
     pp.far_rides = !(pp.progressive && sc.progressive_far == 0);
     pp.with_dupd = nb <= sc.progressive_lauum;
-    if (inverse_done) *inverse_done = pp.progressive ? (pp.with_dupd ? 2 : 1) : (pp.with_trtri ? 1 : 0);
+    if (inverse_done) *inverse_done = pp.progressive ? (pp.with_dupd ? 2 : 1) : 0;
     return pp;
 }
 
-// builds the plan into `out` (NULL: only the size is computed); returns the bytes, 0 on failure
-inline size_t make_plan(int dtype, int n, int q, bool with_inverse, const lcgp_sched& sc, void* out) {
+// first block column of the hosted panels for this shape and schedule (nb: none)
+inline int hosted_from(int dtype, int nb, int q, bool with_inverse, const lcgp_sched& sc) {
+    (void)dtype; (void)q; (void)with_inverse;
+    if (!sc.hosted || !lcgp_fill::HostPlanner::applicable(nb)) return nb;
+    return 0;
+}
+
+// builds the plan into `out` (NULL: only the size is computed) or into `vec` (resized); returns the bytes, 0 on failure
+inline size_t make_plan(int dtype, int n, int q, bool with_inverse, const lcgp_sched& sc, void* out,
+                        std::vector<char>* vec = nullptr) {
     const int npad = round_up(n, 2 * TS), nb = npad / TS;
     int inverse_done = 0;
-    lcgp_fill::Planner plan(plan_params(dtype, nb, q, with_inverse, sc, &inverse_done));
+    lcgp_fill::PlanParams pp = plan_params(dtype, nb, q, with_inverse, sc, &inverse_done);
+    const int hf = hosted_from(dtype, nb, q, with_inverse, sc);
+    if (hf < nb) { pp.stop_block = hf; pp.progressive = false; inverse_done = 0; }
+    lcgp_fill::Planner plan(pp);
     plan.run();
     if (plan.failed) { bad("internal: the filler queue did not drain"); return 0; }
-    lcgp_fill::DagBuilder dag(nb, q);
-    dag.build(plan.launches);
-    const bool dag_ok = !dag.failed && dag.segs.size() * (size_t)q + 16 <= dag_ctl_ints(nb, q);
+    lcgp_fill::HostPlanner hplan(nb, q, sc.hosted_defer, hf / 4);
+    if (hf < nb) {
+        hplan.run();
+        if (hplan.failed) { bad("internal: the hosted plan left a column panel behind"); return 0; }
+    }
     PlanHeader h;
     memset(&h, 0, sizeof(h));
     h.magic = PLAN_MAGIC; h.version = LCGP_VERSION;
     h.dtype = dtype; h.n = n; h.nb = nb; h.q = q; h.with_inverse = with_inverse ? 1 : 0;
     h.nlaunch = (int)plan.launches.size();
-    h.nseg = dag_ok ? (int)dag.segs.size() : 0;
-    h.ntasks = dag_ok ? dag.ntasks : 0;
+    h.npanel = (int)hplan.panels.size();
+    h.host_from = hf;
     h.inverse_done = inverse_done;
     h.sched = sc;
     int dev = 0, ncu = 0;
@@ -2795,29 +2507,14 @@ inline size_t make_plan(int dtype, int n, int q, bool with_inverse, const lcgp_s
     (void)hipGetLastError();
     h.num_cu = ncu;
     h.off_launch = (sizeof(PlanHeader) + 255) & ~size_t(255);
-    // the order of the sequence: the launch order itself (dag = 1), or a list schedule of the graph (dag = 2)
-    std::vector<lcgp_fill::DagRun> runs;
-    double sim_us = 0.0;
-    if (dag_ok) {
-        if (sc.dag == 2 && !(sc.dag_flags & 128)) {
-            lcgp_fill::DagScheduler sch;
-            sch.run(dag.segs, 2 * ncu, plan_params(dtype, nb, q, with_inverse, sc, nullptr).ob);
-            if (!sch.failed) { runs.swap(sch.runs); sim_us = sch.makespan_us; }
-        }
-        if (runs.empty())
-            for (size_t i = 0; i < dag.segs.size(); ++i) runs.push_back({(int)i, 0, dag.segs[i].ntasks, dag.segs[i].t0});
-    }
-    h.nruns = (int)runs.size();
-    h.sim_us = sim_us;
-    h.off_seg = (h.off_launch + sizeof(lcgp_fill::Launch) * h.nlaunch + 255) & ~size_t(255);
-    h.off_run = (h.off_seg + sizeof(DagSeg) * h.nseg + 255) & ~size_t(255);
-    h.bytes = (h.off_run + sizeof(lcgp_fill::DagRun) * h.nruns + 255) & ~size_t(255);
+    h.off_panel = (h.off_launch + sizeof(lcgp_fill::Launch) * h.nlaunch + 255) & ~size_t(255);
+    h.bytes = (h.off_panel + sizeof(HostPanel) * h.npanel + 255) & ~size_t(255);
+    if (vec) { vec->resize(h.bytes); out = vec->data(); }
     if (out) {
         memset(out, 0, h.bytes);
         memcpy(out, &h, sizeof(h));
         memcpy((char*)out + h.off_launch, plan.launches.data(), sizeof(lcgp_fill::Launch) * h.nlaunch);
-        if (h.nseg) memcpy((char*)out + h.off_seg, dag.segs.data(), sizeof(DagSeg) * h.nseg);
-        if (h.nruns) memcpy((char*)out + h.off_run, runs.data(), sizeof(lcgp_fill::DagRun) * h.nruns);
+        if (h.npanel) memcpy((char*)out + h.off_panel, hplan.panels.data(), sizeof(HostPanel) * h.npanel);
     }
     return h.bytes;
 }
@@ -2833,14 +2530,12 @@ inline int check_plan(const void* plan_host, int dtype, int n, int q, bool with_
 // Hosted panels (see host_kernel): per outer panel the launch that factors its diagonal block beside deferred trailing
 // updates, the panel solve of the rows below and the rank-256 update of the next panel's columns.
 template <typename T>
-int do_potrf_hosted(hipStream_t st, const Ws& w, const lcgp_sched& sc) {
+int do_potrf_hosted(hipStream_t st, const Ws& w, const HostPanel* panels, int npanel) {
     T* M = (T*)(w.base + w.off_M);
     T* W = (T*)(w.base + w.off_W);
     T* V = (T*)(w.base + w.off_V);
-    lcgp_fill::HostPlanner plan(w.nb, w.q, sc.hosted_defer);
-    plan.run();
-    if (plan.failed) return bad("internal: the hosted plan left a column panel behind");
-    for (const HostPanel& p : plan.panels) {
+    for (int pi = 0; pi < npanel; ++pi) {
+        const HostPanel& p = panels[pi];
         HostArgs a;
         a.M = M; a.W = W; a.V = V; a.mat = w.mat; a.npad = w.npad; a.nb = w.nb; a.q = w.q;
         a.J = p.J; a.pe = p.pe;
@@ -2855,7 +2550,7 @@ int do_potrf_hosted(hipStream_t st, const Ws& w, const lcgp_sched& sc) {
         g.sA = g.sB = g.sC = w.mat; g.ldA = g.ldB = g.ldC = w.npad;
         g.B = W; g.C = M; g.nb = w.nb; g.p0 = p.J; g.p2 = p.pe; g.q = w.q; g.t0 = 0; g.skipq = 1;
         const int rows = w.nb - p.pe;
-        if (p.J == 0) {        // panel 0 sits in M: in place, block column by block column from the right
+        if (pi == 0) {         // the first hosted panel sits in M: in place, block column by block column from the right
             g.A = M; g.p3 = 0;
             for (int jt = p.pe - p.J - 1; jt >= 0; --jt) {
                 g.p1 = jt;
@@ -2885,12 +2580,11 @@ int do_potrf_hosted(hipStream_t st, const Ws& w, const lcgp_sched& sc) {
 // launches of panel J+1 carry as filler tiles -- the chain leaves >= 97 % of the CUs idle, and a second HIP stream
 // cannot fill them on this platform.  The launch sequence is PLANNED first (fill_sched.h: Planner, host
 // only, replayed on the CPU by tests/test_fill_sched.py through tests/native/dump_plan.cpp) -- by the caller, once
-// (lcgp_plan_build), or here per call when no plan is passed -- and then enqueued launch by launch, or, with a plan
-// whose schedule says so, as the one persistent launch of dag_kernel.
+// (lcgp_plan_build), or here per call when no plan is passed -- and then enqueued launch by launch; the hosted panels
+// of the plan (if any) follow.
 template <typename T>
 int do_potrf(hipStream_t st, const Ws& w, const lcgp_sched& sc, bool stats_zeroed = false, bool with_inverse = false,
-             int* inverse_done = nullptr /* 0 = nothing, 1 = L^-1, 2 = L^-1 and A^-1 */, const void* plan_host = nullptr,
-             const void* plan_dev = nullptr) {
+             int* inverse_done = nullptr /* 0 = nothing, 1 = L^-1, 2 = L^-1 and A^-1 */, const void* plan_host = nullptr) {
     T* M = (T*)(w.base + w.off_M);
     T* W = (T*)(w.base + w.off_W);
     double* logdet = (double*)(w.base + w.off_logdet);
@@ -2900,56 +2594,15 @@ int do_potrf(hipStream_t st, const Ws& w, const lcgp_sched& sc, bool stats_zeroe
         CHECK_LAUNCH("zero_stats");
     }
     const int dtype = sizeof(T) == 4 ? LCGP_F32 : LCGP_F64;
-    {
-        const lcgp_sched& scx = plan_host ? ((const PlanHeader*)plan_host)->sched : sc;
-        if (scx.hosted && lcgp_fill::HostPlanner::applicable(w.nb)) {
-            if (inverse_done) *inverse_done = 0;
-            return do_potrf_hosted<T>(st, w, scx);
-        }
+    std::vector<char> local;
+    if (!plan_host) {
+        if (!make_plan(dtype, w.n, w.q, with_inverse, sc, nullptr, &local)) return -1;
+        plan_host = local.data();
     }
-    const lcgp_fill::Launch* launches = nullptr;
-    int nlaunch = 0;
-    std::vector<lcgp_fill::Launch> local;
-    if (plan_host) {
-        const PlanHeader* h = (const PlanHeader*)plan_host;
-        if (inverse_done) *inverse_done = h->inverse_done;
-        if (h->sched.dag && h->nseg > 0 && plan_dev) {
-            // ONE persistent launch: control words zeroed by a memset node, then as many workgroups as the chip holds
-            int* ctl = (int*)(w.base + w.off_dag);
-            const size_t zb = ((size_t)(DAG_CTL + (size_t)h->nseg * w.q) * sizeof(int) + 15) & ~size_t(15);
-            hipError_t e = hipMemsetAsync(ctl, 0, zb, st);
-            if (e != hipSuccess) return fail("hipMemsetAsync", e);
-            DagArgs a;
-            a.M = M; a.W = W; a.V = w.base + w.off_V; a.mat = w.mat; a.npad = w.npad; a.nb = w.nb; a.q = w.q;
-            a.logdet = logdet; a.info = info;
-            a.segs = (const DagSeg*)((const char*)plan_dev + h->off_seg);
-            a.nseg = h->nseg; a.ntasks = h->ntasks;
-            a.runs = (const lcgp_fill::DagRun*)((const char*)plan_dev + h->off_run);
-            a.nruns = h->nruns;
-            a.ctl = ctl;
-            a.spin_limit = h->sched.dag_spin_limit > 0 ? (unsigned)h->sched.dag_spin_limit : 2000000u;
-            a.flags = h->sched.dag_flags;
-#ifdef LCGP_DAG_TRACE
-            a.trace = (unsigned long long*)(w.base + w.off_trace);
-            a.trace_cap = DAG_TRACE_CAP;
-#endif
-            long grid = 2L * h->num_cu;
-            if (grid > h->ntasks) grid = h->ntasks;
-            if (a.flags & 8) hipLaunchKernelGGL((dag_kernel<T, false>), dim3((unsigned)grid), dim3(256), 0, st, a);
-            else hipLaunchKernelGGL((dag_kernel<T, true>), dim3((unsigned)grid), dim3(256), 0, st, a);
-            CHECK_LAUNCH("dag_kernel");
-            return 0;
-        }
-        launches = (const lcgp_fill::Launch*)((const char*)plan_host + h->off_launch);
-        nlaunch = h->nlaunch;
-    } else {
-        lcgp_fill::Planner plan(plan_params(dtype, w.nb, w.q, with_inverse, sc, inverse_done));
-        plan.run();
-        if (plan.failed) return bad("internal: the filler queue did not drain");
-        local.swap(plan.launches);
-        launches = local.data();
-        nlaunch = (int)local.size();
-    }
+    const PlanHeader* h = (const PlanHeader*)plan_host;
+    if (inverse_done) *inverse_done = h->inverse_done;
+    const lcgp_fill::Launch* launches = (const lcgp_fill::Launch*)((const char*)plan_host + h->off_launch);
+    const int nlaunch = h->nlaunch;
     for (int li = 0; li < nlaunch; ++li) {
         const lcgp_fill::Launch& l = launches[li];
         FillSet fs = l.fs;
@@ -2970,8 +2623,8 @@ int do_potrf(hipStream_t st, const Ws& w, const lcgp_sched& sc, bool stats_zeroe
                 a.M = M; a.W = W; a.mat = w.mat; a.npad = w.npad; a.nb = w.nb;
                 a.c = l.c; a.J = l.J; a.pe = l.pe; a.q = w.q;
                 a.diag_end = l.diag_end; a.has_special = l.has_special; a.n_trmm = l.n_trmm; a.n_upd = l.n_upd;
-                a.trmm_r0 = l.trmm_r0 ? l.trmm_r0 : l.c + 1;
-                a.upd_r0 = l.upd_r0 ? l.upd_r0 : l.c + 2;
+                a.trmm_r0 = l.c + 1;
+                a.upd_r0 = l.c + 2;
                 a.logdet = logdet; a.info = info;
                 a.fs = fs;
                 const long nblk = (long)(a.n_trmm + a.n_upd) * w.q + fs.nblk;
@@ -2980,44 +2633,14 @@ int do_potrf(hipStream_t st, const Ws& w, const lcgp_sched& sc, bool stats_zeroe
                 break;
             }
             case lcgp_fill::L_TRAIL:
-                rc = potrf_trailing<T>(st, w, l.J, l.pe, l.c_lo, l.c_hi, l.tiles128 != 0, l.with_leaf != 0, l.t_first, l.t_count, l.r_lo, l.r_hi);
+                rc = potrf_trailing<T>(st, w, l.J, l.pe, l.c_lo, l.c_hi, l.tiles128 != 0, l.with_leaf != 0);
                 break;
-            case lcgp_fill::L_PSOLVE: {
-                GemmArgs g;
-                g.sA = g.sB = g.sC = w.mat; g.ldA = g.ldB = g.ldC = w.npad;
-                g.A = M; g.B = W; g.C = M;
-                g.q = w.q; g.t0 = 0; g.skipq = 1; g.nb = w.npad / 128;
-                g.p0 = l.J / 2; g.p1 = l.c_lo; g.p2 = l.r_lo / 2; g.p3 = 0;
-                const int nt = (w.nb - l.r_lo) / 2;
-                if (nt > 0) hipLaunchKernelGGL((tile_gemm<T, OP_PSOLVE, 128, 8>), dim3((unsigned)nt * w.q), dim3(512), 0, st, g);
-                CHECK_LAUNCH("tile_gemm");
-                break;
-            }
-            case lcgp_fill::L_TRI: {
-                GemmArgs g;
-                g.sA = g.sB = g.sC = w.mat; g.ldA = g.ldB = g.ldC = w.npad;
-                g.p0 = l.tri_mb; g.p1 = l.tri_np; g.p2 = l.tri_p0; g.p3 = 0;
-                if (l.tri_w == 0) { g.A = M; g.B = W; g.C = w.base + w.off_V; }
-                else { g.A = W; g.B = w.base + w.off_V; g.C = W; }
-                const int nt = l.tri_np * l.tri_mb * l.tri_mb;
-                g.q = w.q; g.t0 = 0; g.skipq = 1;
-                if (l.tiles128) {
-                    g.nb = w.npad / 128;
-                    if (l.tri_w == 0) hipLaunchKernelGGL((tile_gemm<T, OP_TRTRI_T, 128, 8>), dim3((unsigned)nt * w.q), dim3(512), 0, st, g);
-                    else hipLaunchKernelGGL((tile_gemm<T, OP_TRTRI_W, 128, 8>), dim3((unsigned)nt * w.q), dim3(512), 0, st, g);
-                } else {
-                    g.nb = w.nb;
-                    if (l.tri_w == 0) hipLaunchKernelGGL((tile_gemm<T, OP_TRTRI_T, 64, 4>), dim3((unsigned)nt * w.q), dim3(256), 0, st, g);
-                    else hipLaunchKernelGGL((tile_gemm<T, OP_TRTRI_W, 64, 4>), dim3((unsigned)nt * w.q), dim3(256), 0, st, g);
-                }
-                CHECK_LAUNCH("tile_gemm");
-                break;
-            }
             default:
                 rc = launch_fill<T>(st, fs);
         }
         if (rc) return rc;
     }
+    if (h->npanel > 0) return do_potrf_hosted<T>(st, w, (const HostPanel*)((const char*)plan_host + h->off_panel), h->npanel);
     return 0;
 }
 
@@ -3103,13 +2726,13 @@ void launch_grad(hipStream_t st, const Ws& w, const void* x, const void* sr, con
 
 template <typename T>
 int do_nll_grad(hipStream_t st, const Ws& w, const lcgp_sched& sc, const void* x, const void* Y, const void* sr,
-                const double* theta, double* out, const void* plan_host, const void* plan_dev) {
+                const double* theta, double* out, const void* plan_host) {
     int rc = do_build<T>(st, w, x, sr, theta, Y);
     if (rc) return rc;
     T* b = (T*)(w.base + w.off_b);
     T* z = (T*)(w.base + w.off_z);
     int inverse_done = 0;          // what the progressive inverse has left behind the factorisation: 1 = L^-1, 2 = and A^-1
-    rc = do_potrf<T>(st, w, sc, true, true, &inverse_done, plan_host, plan_dev);
+    rc = do_potrf<T>(st, w, sc, true, true, &inverse_done, plan_host);
     if (rc) return rc;
     bool z_partials = false;       // z = A^-1 b: per-tile partials from the 128-tile LAUUM's epilogue, or a pass of its own
     if (inverse_done == 0) rc = do_potri<T>(st, w, sc, &z_partials);
@@ -3232,7 +2855,7 @@ inline int predict_pad(int n0) { return n0 >= 128 ? round_up(n0, 2 * TS) : round
 // kernel, k tiles only up to the diagonal: W is lower triangular), then the row reductions.
 template <typename T>
 int do_predict(hipStream_t st, const Ws& w, const void* x, const void* sr, const double* theta, int n0, const void* x0,
-               int same, void* scratch, double* ghat, double* gvar) {
+               int same, void* scratch, double* ghat, double* gvar, int ldo) {
     const int n0pad = predict_pad(n0);
     const size_t slab = (size_t)n0pad * w.npad;
     T* X = (T*)scratch;                 // q slabs n0pad x npad : c0k o sr^T (zero padded)
@@ -3257,7 +2880,7 @@ int do_predict(hipStream_t st, const Ws& w, const void* x, const void* sr, const
     }
     if (rc) return rc;
     hipLaunchKernelGGL((pred_reduce_kernel<T>), dim3(n0, w.q), dim3(64), 0, st, (const T*)X, (const T*)U, slab, w.npad, w.n,
-                       (const T*)(w.base + w.off_z), w.npad, theta, tw, w.d, n0, ghat, gvar);
+                       (const T*)(w.base + w.off_z), w.npad, theta, tw, w.d, ldo, ghat, gvar);
     CHECK_LAUNCH("pred_reduce_kernel");
     return 0;
 }
@@ -3330,7 +2953,8 @@ int lcgp_kernel_build(void* stream, int dtype, int n, int d, int p, int q_local,
 }
 
 int lcgp_potrf_logdet(void* stream, int dtype, int n, int d, int p, int q_local, void* workspace, double* half_logdet,
-                      int* info, const lcgp_sched* sched, const void* plan_host, const void* plan_dev) {
+                      int* info, const lcgp_sched* sched, const void* plan) {
+    const void* plan_host = plan;
     int rc = check_common(dtype, n, d, p, q_local);
     if (rc) return rc;
     if (!workspace) return bad("NULL workspace");
@@ -3339,8 +2963,8 @@ int lcgp_potrf_logdet(void* stream, int dtype, int n, int d, int p, int q_local,
     if (plan_host && (rc = check_plan(plan_host, dtype, n, q_local, false))) return rc;
     Ws w = carve(dtype, n, d, p, q_local, workspace);
     hipStream_t st = (hipStream_t)stream;
-    rc = dtype == LCGP_F64 ? do_potrf<double>(st, w, sc, false, false, nullptr, plan_host, plan_dev)
-                           : do_potrf<float>(st, w, sc, false, false, nullptr, plan_host, plan_dev);
+    rc = dtype == LCGP_F64 ? do_potrf<double>(st, w, sc, false, false, nullptr, plan_host)
+                           : do_potrf<float>(st, w, sc, false, false, nullptr, plan_host);
     if (rc) return rc;
     if (half_logdet || info) {
         hipLaunchKernelGGL(copy_stats_kernel, dim3((q_local + 63) / 64), dim3(64), 0, st,
@@ -3416,7 +3040,8 @@ int lcgp_fetch_vector(void* stream, int dtype, int n, int d, int p, int q_local,
 
 int lcgp_nll_grad(void* stream, int dtype, int n, int d, int p, int q_local, const void* x, const void* Y,
                   const void* sr, const double* theta, void* workspace, double* out, const lcgp_sched* sched,
-                  const void* plan_host, const void* plan_dev) {
+                  const void* plan) {
+    const void* plan_host = plan;
     int rc = check_common(dtype, n, d, p, q_local);
     if (rc) return rc;
     if (!x || !Y || !theta || !workspace || !out) return bad("NULL pointer");
@@ -3429,8 +3054,8 @@ int lcgp_nll_grad(void* stream, int dtype, int n, int d, int p, int q_local, con
         return rc;
     }
     Ws w = carve(dtype, n, d, p, q_local, workspace);
-    return dtype == LCGP_F64 ? do_nll_grad<double>((hipStream_t)stream, w, sc, x, Y, sr, theta, out, plan_host, plan_dev)
-                             : do_nll_grad<float>((hipStream_t)stream, w, sc, x, Y, sr, theta, out, plan_host, plan_dev);
+    return dtype == LCGP_F64 ? do_nll_grad<double>((hipStream_t)stream, w, sc, x, Y, sr, theta, out, plan_host)
+                             : do_nll_grad<float>((hipStream_t)stream, w, sc, x, Y, sr, theta, out, plan_host);
 }
 
 int lcgp_plan_bytes(int dtype, int n, int q_local, int with_inverse, const lcgp_sched* sched, size_t* bytes) {
@@ -3455,13 +3080,12 @@ int lcgp_plan_build(int dtype, int n, int q_local, int with_inverse, const lcgp_
     return make_plan(dtype, n, q_local, with_inverse != 0, sc, plan) ? 0 : -1;
 }
 
-int lcgp_plan_info(const void* plan, int* nlaunch, int* nseg, int* ntasks, int* inverse_done) {
+int lcgp_plan_info(const void* plan, int* nlaunch, int* npanel, int* inverse_done) {
     if (!plan) return bad("plan is NULL");
     const PlanHeader* h = (const PlanHeader*)plan;
     if (h->magic != PLAN_MAGIC || h->version != LCGP_VERSION) return bad("plan: not a plan of this library version");
     if (nlaunch) *nlaunch = h->nlaunch;
-    if (nseg) *nseg = h->nseg;
-    if (ntasks) *ntasks = h->ntasks;
+    if (npanel) *npanel = h->npanel;
     if (inverse_done) *inverse_done = h->inverse_done;
     return 0;
 }
@@ -3479,15 +3103,17 @@ int lcgp_pack_partial(void* stream, int d, int p, int q_local, int q_total, cons
 
 int lcgp_predict(void* stream, int dtype, int n, int d, int p, int q_local, const void* x, const void* sr,
                  const double* theta, const void* workspace, int n0, const void* x0, int same, void* scratch,
-                 double* ghat, double* gvar) {
+                 double* ghat, double* gvar, int out_stride) {
     int rc = check_common(dtype, n, d, p, q_local);
     if (rc) return rc;
     if (n0 < 1) return bad("n0 < 1");
     if (!x || !theta || !workspace || !x0 || !scratch || !ghat || !gvar) return bad("NULL pointer");
+    if (out_stride != 0 && out_stride < n0) return bad("out_stride must be 0 (= n0) or >= n0");
+    const int ldo = out_stride ? out_stride : n0;
     Ws w = carve(dtype, n, d, p, q_local, (void*)workspace);
     hipStream_t st = (hipStream_t)stream;
-    return dtype == LCGP_F64 ? do_predict<double>(st, w, x, sr, theta, n0, x0, same, scratch, ghat, gvar)
-                             : do_predict<float>(st, w, x, sr, theta, n0, x0, same, scratch, ghat, gvar);
+    return dtype == LCGP_F64 ? do_predict<double>(st, w, x, sr, theta, n0, x0, same, scratch, ghat, gvar, ldo)
+                             : do_predict<float>(st, w, x, sr, theta, n0, x0, same, scratch, ghat, gvar, ldo);
 }
 
 }  // extern "C"

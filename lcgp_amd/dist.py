@@ -54,7 +54,7 @@ def local_components(q: int, rank: int, world: int):
     return list(range(rank, q, world))
 
 
-_PINNED = {}      # (device index, length) -> pinned float64 row for the one device-to-host copy of an evaluation
+_PINNED = {}      # device index -> ONE growable pinned float64 row for the device-to-host copy of an evaluation / prediction
 
 
 def reduce_to_host(t, group=None):
@@ -70,15 +70,16 @@ def reduce_to_host(t, group=None):
             t = t.cpu()          # gloo rehearsal of a GPU job: the collective runs on host memory
         dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
     if t.is_cuda:
-        # one asynchronous copy into a pinned row kept per (device, length) and one stream synchronisation: no pageable
-        # staging buffer and no allocation per evaluation
-        key = (t.device.index, t.numel())
-        pin = _PINNED.get(key)
-        if pin is None:
-            pin = _PINNED[key] = torch.empty(t.numel(), dtype=torch.float64).pin_memory()
-        pin.copy_(t.reshape(-1), non_blocking=True)
+        # one asynchronous copy into the device's pinned row (reallocated only when a longer vector comes along: the page-locked
+        # memory of a serving loop with varying prediction batch sizes stays bounded by the largest one) and one stream
+        # synchronisation: no pageable staging buffer and no allocation per evaluation
+        n = t.numel()
+        pin = _PINNED.get(t.device.index)
+        if pin is None or pin.numel() < n:
+            pin = _PINNED[t.device.index] = torch.empty(max(n, 256), dtype=torch.float64).pin_memory()
+        pin[:n].copy_(t.reshape(-1), non_blocking=True)
         torch.cuda.current_stream(t.device).synchronize()
-        return pin.numpy().reshape(tuple(t.shape)).copy()
+        return pin[:n].numpy().reshape(tuple(t.shape)).copy()
     return t.cpu().numpy()
 
 

@@ -46,7 +46,7 @@ class HotPathEngine:
         assert all(0 <= k < self.q_total for k in comp_ids)
         self._sched_obj = None       # an _hip.Sched to override the launch schedule (tests / tools); None = defaults
         self.use_plan = True         # the launch plan is built once per schedule (lcgp_plan_build) and passed with every call
-        self._plan_cache = {}        # with_inverse -> (host block, device copy)
+        self._plan_cache = {}        # with_inverse -> host block
         with torch.cuda.device(self.device):
             self.x = torch.as_tensor(x).to(self.device, self.tdtype).contiguous()
             self.Y = torch.as_tensor(Y).to(self.device, self.tdtype).contiguous()
@@ -97,33 +97,41 @@ class HotPathEngine:
     def _sched(self):
         return None if self._sched_obj is None else C.byref(self._sched_obj)
 
-    def plan(self, with_inverse=True):
-        """(host pointer, device pointer) of the launch plan of the factorisation for the current schedule: planned ONCE
-        (lcgp_plan_build), the position-independent block kept in host memory and copied to the device once; both are
-        passed with every evaluation.  (None, None) with `use_plan = False`: the library then plans per call."""
-        if not self.use_plan:
-            return C.c_void_p(0), C.c_void_p(0)
+    def _build_plan(self, with_inverse):
+        """the launch plan of the factorisation for the current schedule as a numpy byte block (lcgp_plan_build); built inside
+        the engine's device context: the plan records the CU count of the CURRENT device"""
         key = bool(with_inverse)
-        if key not in self._plan_cache:
-            torch = self.torch
-            nbytes = C.c_size_t(0)
+        nbytes = C.c_size_t(0)
+        with self.torch.cuda.device(self.device):
             _hip.check(self.lib.lcgp_plan_bytes(self.dtype, self.n, self.q_local, int(key), self._sched(), C.byref(nbytes)),
                        "lcgp_plan_bytes")
             host = np.zeros(int(nbytes.value), dtype=np.uint8)
             _hip.check(self.lib.lcgp_plan_build(self.dtype, self.n, self.q_local, int(key), self._sched(),
                                                 C.c_void_p(host.ctypes.data), nbytes), "lcgp_plan_build")
-            with torch.cuda.device(self.device):
-                dev = torch.from_numpy(host).to(self.device)
-            self._plan_cache[key] = (host, dev)
-        host, dev = self._plan_cache[key]
-        return C.c_void_p(host.ctypes.data), C.c_void_p(dev.data_ptr())
+        return host
+
+    def plan(self, with_inverse=True):
+        """host pointer of the launch plan of the factorisation for the current schedule: planned ONCE (lcgp_plan_build), the
+        position-independent block kept in host memory and passed with every evaluation.  NULL with `use_plan = False`:
+        the library then plans per call."""
+        if not self.use_plan:
+            return C.c_void_p(0)
+        key = bool(with_inverse)
+        if key not in self._plan_cache:
+            self._plan_cache[key] = self._build_plan(key)
+        return C.c_void_p(self._plan_cache[key].ctypes.data)
 
     def plan_info(self, with_inverse=True):
-        """launches / segments / tasks / what the plan leaves behind the factorisation (lcgp_plan_info)"""
-        ph, _ = self.plan(with_inverse)
-        v = [C.c_int(0) for _ in range(4)]
-        _hip.check(self.lib.lcgp_plan_info(ph, *[C.byref(x) for x in v]), "lcgp_plan_info")
-        return dict(zip(("launches", "segments", "tasks", "inverse_done"), (x.value for x in v)))
+        """launches / hosted panels / what the plan leaves behind the factorisation (lcgp_plan_info)"""
+        key = bool(with_inverse)
+        host = self._plan_cache.get(key) if self.use_plan else None
+        if host is None:
+            host = self._build_plan(key)        # (use_plan = False: a temporary plan, what the library would plan per call)
+            if self.use_plan:
+                self._plan_cache[key] = host
+        v = [C.c_int(0) for _ in range(3)]
+        _hip.check(self.lib.lcgp_plan_info(C.c_void_p(host.ctypes.data), *[C.byref(x) for x in v]), "lcgp_plan_info")
+        return dict(zip(("launches", "hosted_panels", "inverse_done"), (x.value for x in v)))
 
     def upload_theta(self, theta_rows, guard=0.0, stream=None):
         torch = self.torch
@@ -157,14 +165,12 @@ class HotPathEngine:
     def enqueue(self, stream=None):
         """One pass of the hot path over the resident theta block (asynchronous)."""
         if stream is not None:                    # (inside the device context already)
-            ph, pd = self.plan(True)
             _hip.check(self.lib.lcgp_nll_grad(C.c_void_p(stream.cuda_stream), self.dtype, self.n, self.d, self.p, self.q_local,
-                                              *self._nll_args(), self._sched(), ph, pd), "lcgp_nll_grad")
+                                              *self._nll_args(), self._sched(), self.plan(True)), "lcgp_nll_grad")
             return
         with self.torch.cuda.device(self.device):
-            ph, pd = self.plan(True)
             _hip.check(self.lib.lcgp_nll_grad(self._stream(), self.dtype, self.n, self.d, self.p, self.q_local,
-                                              *self._nll_args(), self._sched(), ph, pd),
+                                              *self._nll_args(), self._sched(), self.plan(True)),
                        "lcgp_nll_grad")
 
     def evaluate(self, theta_rows):
@@ -192,8 +198,8 @@ class HotPathEngine:
             self._theta_last, np.asarray(theta_rows, np.float64).reshape(self.q_local, self.tw))
 
     # ------------------------------------------------------------------------------------------------
-    def predict_device(self, x0s, same=False):
-        """ghat, gvar (q_local, n0) float64 DEVICE tensors for standardised x0s, from the factorisation of the last
+    def predict_block(self, x0s, same=False):
+        """(2, q_local, n0) float64 DEVICE tensor [ghat; gvar] for standardised x0s, from the factorisation of the last
         evaluate().  x0 is processed in chunks of PREDICT_CHUNK rows with one engine-owned scratch buffer."""
         torch = self.torch
         if self._theta_last is None:
@@ -210,22 +216,27 @@ class HotPathEngine:
             if self._scratch is None or self._scratch.numel() < nbytes.value:
                 self._scratch = None
                 self._scratch = torch.empty(int(nbytes.value), dtype=torch.uint8, device=self.device)
-            ghat = torch.empty((self.q_local, n0), dtype=torch.float64, device=self.device)
-            gvar = torch.empty((self.q_local, n0), dtype=torch.float64, device=self.device)
+            # ONE (2, q_local, n0) result block; every chunk writes its columns in place (row stride = n0): no per-chunk
+            # temporaries, no device-to-device copies
+            out = torch.empty((2, self.q_local, n0), dtype=torch.float64, device=self.device)
+            ghat, gvar = out[0], out[1]
+            st, xp, srp, thp, wsp, scp = self._stream(), self._p(self.x), self._p(self.sr), self._p(self.theta_dev), \
+                self._p(self.workspace), self._p(self._scratch)
             for lo in range(0, n0, chunk):
                 m = min(chunk, n0 - lo)
                 # the nugget term only exists when x0 IS the training set (covmat.py:46-51): then n0 == n and the
                 # diagonal of the full cross matrix falls on rows lo .. lo+m of this chunk
-                gh = torch.empty((self.q_local, m), dtype=torch.float64, device=self.device)
-                gv = torch.empty((self.q_local, m), dtype=torch.float64, device=self.device)
-                _hip.check(self.lib.lcgp_predict(self._stream(), self.dtype, self.n, self.d, self.p, self.q_local,
-                                                 self._p(self.x), self._p(self.sr), self._p(self.theta_dev),
-                                                 self._p(self.workspace), m, C.c_void_p(x0d.data_ptr() + lo * self.d * x0d.element_size()),
-                                                 (1 + lo) if same else 0,
-                                                 self._p(self._scratch), self._p(gh), self._p(gv)), "lcgp_predict")
-                ghat[:, lo:lo + m] = gh
-                gvar[:, lo:lo + m] = gv
-            return ghat, gvar
+                _hip.check(self.lib.lcgp_predict(st, self.dtype, self.n, self.d, self.p, self.q_local, xp, srp, thp, wsp, m,
+                                                 C.c_void_p(x0d.data_ptr() + lo * self.d * x0d.element_size()),
+                                                 (1 + lo) if same else 0, scp,
+                                                 C.c_void_p(ghat.data_ptr() + 8 * lo), C.c_void_p(gvar.data_ptr() + 8 * lo), n0),
+                           "lcgp_predict")
+            return out
+
+    def predict_device(self, x0s, same=False):
+        """ghat, gvar (q_local, n0): the two halves of predict_block()"""
+        out = self.predict_block(x0s, same)
+        return out[0], out[1]
 
     def predict(self, x0s, same=False):
         ghat, gvar = self.predict_device(x0s, same)

@@ -431,12 +431,13 @@ class LCGP:
         evaluation loop reads these at every step, and an in-place change by a caller (torch bumps `_version`) or a new
         tensor object invalidates the cached copy."""
         t = getattr(self, name)
-        key = (id(t), getattr(t, '_version', None))
+        ver = getattr(t, '_version', None)
         hit = self._np_cache.get(name)
-        if hit is None or hit[0] != key:
-            hit = (key, _np(t))
+        # (the entry holds the tensor itself: an id() alone could be that of a freed tensor's successor)
+        if hit is None or hit[0] is not t or hit[1] != ver:
+            hit = (t, ver, _np(t))
             self._np_cache[name] = hit
-        return hit[1]
+        return hit[2]
 
     def _flat_transform(self):
         """constrained values and d constrained / d unconstrained of the three bounded blocks (lLmb, lLmb0, lnugGPs) in flat order,
@@ -445,13 +446,14 @@ class LCGP:
         q, d = int(self.q), int(self.d)
         if not all(type(par.transform) is SoftClip for par in (self.lLmb, self.lLmb0, self.lnugGPs)):
             return None                  # (a caller has replaced a transform: the per-parameter path serves any bijector)
-        key = tuple((id(par.transform), par.transform.low, par.transform.high) for par in (self.lLmb, self.lLmb0, self.lnugGPs))
-        if self._bounds_cache is None or self._bounds_cache[0] != key:
+        trs = tuple(par.transform for par in (self.lLmb, self.lLmb0, self.lnugGPs))
+        key = tuple((tr.low, tr.high) for tr in trs)
+        if self._bounds_cache is None or self._bounds_cache[0] != key or any(a is not b for a, b in zip(self._bounds_cache[5], trs)):
             lo = np.concatenate([np.full(n_, par.transform.low, F64) for par, n_ in ((self.lLmb, q * d), (self.lLmb0, q), (self.lnugGPs, q))])
             hi = np.concatenate([np.full(n_, par.transform.high, F64) for par, n_ in ((self.lLmb, q * d), (self.lLmb0, q), (self.lnugGPs, q))])
             cc = np.concatenate([np.full(n_, par.transform._c, F64) for par, n_ in ((self.lLmb, q * d), (self.lLmb0, q), (self.lnugGPs, q))])
-            self._bounds_cache = (key, lo, hi, hi - lo, cc)
-        _, lo, hi, w, cc = self._bounds_cache
+            self._bounds_cache = (key, lo, hi, hi - lo, cc, trs)        # (holds the transforms: no id() reuse)
+        _, lo, hi, w, cc, _ = self._bounds_cache
         u = np.concatenate([self.lLmb.unconstrained.reshape(-1), self.lLmb0.unconstrained, self.lnugGPs.unconstrained])
         return softclip_flat(u, lo, hi, w, cc)
 
@@ -529,11 +531,6 @@ class LCGP:
         if self._float64_only:
             eng = self._engine64
         vec = reduced(eng)
-        if vec[1] < 0:
-            # not a property of the matrix: a wait inside the persistent factorisation launch expired (lcgp_sched.dag,
-            # include/lcgp_hip.h) and the launch drained with info = -1 on every component
-            raise RuntimeError('lcgp_amd: the persistent factorisation launch gave up a wait (info=%g); '
-                               'nothing was computed at these parameters' % vec[1])
         if self._float64_only:
             self._last_eval_float64 = True
         elif (vec[1] != 0 or not np.isfinite(vec[0])) and self._dtype == 'float32' and self.float32_fallback:
@@ -543,9 +540,12 @@ class LCGP:
             if self._engine64 is None and eng is not None:
                 self._engine64 = self._make_engine('float64')
             self.float32_fallbacks += 1
-            self._f32_consecutive += 1
             vec = reduced(self._engine64)
             self._last_eval_float64 = True
+            # only a point that float64 CAN evaluate says something about float32: one that is not positive definite in
+            # either precision (a line-search trial at a SoftClip edge) leaves the counter alone
+            if vec[1] == 0 and np.isfinite(vec[0]):
+                self._f32_consecutive += 1
             if self.float32_switch_after and self._f32_consecutive >= self.float32_switch_after:
                 # float32 is not carrying this model: stay on the float64 engine, give the float32 workspace back
                 self._float64_only = True
@@ -597,6 +597,7 @@ class LCGP:
             raise ValueError("Invalid submethod. Choices are 'full' or 'rep'.")
         u0 = self._get_flat()
         last = []
+        self._f32_consecutive = 0          # (a run of float64 repeats does not carry over from an earlier fit)
         if self._dtype == 'float32' and self.float32_fallback and not self._float64_only and self._engine64 is None:
             # the float64 engine behind the fallback is created BEFORE the optimiser starts: if its workspace does not fit,
             # that surfaces here, on every rank, and not in the middle of a run that has already made progress
@@ -725,8 +726,7 @@ class LCGP:
         same = (x0s.shape == xtrain.shape) and bool(np.all(x0s == xtrain))
         n0, q = x0s.shape[0], int(self.q)
         if eng is not None and not _dist.use_collectives(self._group):
-            gh, gv = eng.predict_device(x0s, same)
-            both = torch.stack([gh, gv]).cpu().numpy()
+            both = eng.predict_block(x0s, same).cpu().numpy()
         else:
             full = self._zeros_on_device((2, q, n0))
             if eng is not None:

@@ -61,6 +61,10 @@ class OracleEngine:
         gh, gv = self.predict(x0s, same)
         return torch.as_tensor(gh), torch.as_tensor(gv)
 
+    def predict_block(self, x0s, same=False):
+        import torch
+        return torch.stack(self.predict_device(x0s, same))
+
     def predict(self, x0s, same=False):
         n0 = x0s.shape[0]
         gh = np.zeros((self.q_local, n0))

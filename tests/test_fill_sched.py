@@ -24,42 +24,28 @@ def dump_plan(tmp_path_factory):
                     os.path.join(ROOT, 'tests', 'native', 'dump_plan.cpp')], check=True)
 
     def run(nb, q, ob, syrk_small=2000, fill_leaf=248, fill_step=248, leaf_in_wide=1024, progressive=1, far_rides=1, with_dupd=1,
-            dag=0, interleaved=0, with_trtri=0, trtri_all_small=0, fill_wide=0):
+            host_from=-1, defer=2):
         out = subprocess.run([exe] + [str(v) for v in (nb, q, ob, syrk_small, fill_leaf, fill_step, leaf_in_wide, progressive,
-                                                       far_rides, with_dupd, dag, interleaved, with_trtri, trtri_all_small, fill_wide)],
+                                                       far_rides, with_dupd, host_from, defer)],
                              check=True, capture_output=True, text=True).stdout
         assert 'FAILED' not in out
-        launches = []
-        segs = []
-        runs = []
+        launches, panels = [], []
         for line in out.splitlines():
             f = line.split()
-            d = {}
-            deps = []
-            for kv in f[1:]:
-                k, _, v = kv.partition('=')
-                if k == 'deps':
-                    deps = [tuple(int(y) for y in x.split(':')) for x in v.split(',') if x]
-                else:
-                    d[k] = int(v)
-            if f[0] == 'R':
-                runs.append(d)
-            elif f[0] == 'M':
-                continue
-            elif f[0] == 'L':
+            d = {k: int(v) for k, _, v in (kv.partition('=') for kv in f[1:])}
+            if f[0] == 'L':
                 d['jobs'] = []
                 launches.append(d)
             elif f[0] == 'J':
                 d['t0'] = d.pop('jt0')
                 launches[-1]['jobs'].append(d)
+            elif f[0] == 'H':
+                d['jobs'] = []
+                panels.append(d)
             else:
-                assert len(deps) == d['ndeps']
-                d['deps'] = deps
-                d['jobs'] = [dict(type=d['type'], nblk=d['nblk'], t0=d['jt0'], R0=d['R0'], R1=d['R1'], j0=d['j0'], j1=d['j1'],
-                                  kb0=d['kb0'], kb1=d['kb1'], wide=d.get('wide', 0))] if d['kind'] == 4 else []
-                segs.append(d)
-        run.last_runs = runs
-        return (launches, segs) if dag else launches
+                assert f[0] == 'U'
+                panels[-1]['jobs'].append(d)
+        return (launches, panels) if host_from >= 0 else launches
     return run
 
 
@@ -126,10 +112,8 @@ class Replay:
 
     def run_step(self, l):
         nb, c, J = self.nb, l['c'], l['J']
-        t0 = l.get('trmm_r0') or c + 1          # first block row of the solve tiles / of the delayed-update tiles
-        u0 = l.get('upd_r0') or c + 2
-        if not l.get('trmm_r0'):
-            assert l['n_trmm'] == nb - 1 - c
+        t0, u0 = c + 1, c + 2                   # first block row of the solve tiles / of the delayed-update tiles
+        assert l['n_trmm'] == nb - 1 - c
         assert t0 + l['n_trmm'] <= nb and u0 + l['n_upd'] <= nb
         if l['has_special']:
             assert t0 == c + 1
@@ -147,8 +131,7 @@ class Replay:
                 else:
                     self.wr('M', r, r, D)
         if l['n_upd']:
-            if not l.get('upd_r0'):
-                assert l['n_upd'] == nb - (c + 1) - 1
+            assert l['n_upd'] == nb - (c + 1) - 1
             for r in range(u0, u0 + l['n_upd']):
                 self.new_item()
                 t = self.rd('M', r, r + 1, c + 1, c + 2).copy()
@@ -158,26 +141,6 @@ class Replay:
 
     def run_trail(self, l):
         J, pe = l['J'], l['pe']
-        if l.get('t_count', 0) or l.get('r_lo', 0) or l.get('r_hi', 0):
-            # tiles [t_first, t_first + t_count) of a region: column-major over the tile columns [c_lo, c_hi), in column C the
-            # tile rows [max(C, r_lo), r_hi) (gemm_body, OP_SYRK); on 128x128 tiles a tile is 2 x 2 blocks (3 on the diagonal)
-            u = 2 if l['tiles128'] else 1
-            nbt = self.nb // u
-            rlo, rhi = l.get('r_lo', 0) // u, (l.get('r_hi', 0) // u) or nbt
-            tiles = []
-            for C in range(l['c_lo'] // u, l['c_hi'] // u):
-                for r in range(max(C, rlo), rhi):
-                    tiles.append((r, C))
-            cnt = l.get('t_count', 0) or len(tiles)
-            first = l.get('t_first', 0)
-            assert first + cnt <= len(tiles)
-            for r, C in tiles[first:first + cnt]:
-                self.new_item()
-                for cc in range(C * u, (C + 1) * u):
-                    for rr in range(max(r * u, cc), (r + 1) * u):
-                        t = self.rd('M', rr, rr + 1, cc, cc + 1) - self.rd('M', rr, rr + 1, J, pe) @ self.rd('M', cc, cc + 1, J, pe).T
-                        self.wr('M', rr, cc, t)
-            return
         for C in range(l['c_lo'], l['c_hi']):
             for r in range(C, self.nb):
                 self.new_item()
@@ -194,32 +157,7 @@ class Replay:
             ty, kb0, kb1 = jb['type'], jb['kb0'], jb['kb1']
             for t in range(jb['t0'], jb['t0'] + jb['nblk'] // q):
                 self.new_item()
-                if ty == 1 and jb.get('wide'):       # SYRK on 128 x 128 tiles: column pairs
-                    j, tt = jb['j0'], t
-                    assert j % 2 == 0 and jb['j1'] % 2 == 0
-                    while tt >= jb['R1'] - (j >> 1):
-                        tt -= jb['R1'] - (j >> 1)
-                        j += 2
-                    R = (j >> 1) + tt
-                    assert j < jb['j1'] and R < nb // 2
-                    v = self.rd('M', 2 * R, 2 * R + 2, j, j + 2) - self.rd('M', 2 * R, 2 * R + 2, kb0, kb1) @ self.rd('M', j, j + 2, kb0, kb1).T
-                    if R == j >> 1:     # the diagonal tile: only its lower blocks are data (the kernel rewrites the upper one too)
-                        self.wr('M', 2 * R, j, v[:, :TS])
-                        self.wr('M', 2 * R + 1, j + 1, v[TS:, TS:])
-                    else:
-                        self.wr('M', 2 * R, j, v)
-                elif ty == 3 and jb.get('wide'):     # CUPD on 128 x 128 tiles
-                    assert jb['j0'] % 2 == 0 and jb['j1'] % 2 == 0 and kb0 % 2 == 0
-                    nc = (jb['j1'] - jb['j0']) // 2
-                    R, j = jb['R0'] + t // nc, jb['j0'] + 2 * (t % nc)
-                    assert R < jb['R1']
-                    own = j >= kb0
-                    ks = j if own else kb0
-                    v = self.rd('M', 2 * R, 2 * R + 2, ks, kb1) @ self.rd('W', ks, kb1, j, j + 2)
-                    if not own:
-                        v = v + self.rd('V', 2 * R, 2 * R + 2, j, j + 2)
-                    self.wr('V', 2 * R, j, v)
-                elif ty == 1:       # SYRK
+                if ty == 1:         # SYRK
                     j, tt = jb['j0'], t
                     while tt >= jb['R1'] - (j >> 1):
                         tt -= jb['R1'] - (j >> 1)
@@ -279,40 +217,6 @@ class Replay:
                             acc += self.rd('W', R0 + rl, R0 + rl + 1, R0 + kt, R0 + kt + 1) @ self.rd('V', R0 + kt, R0 + kt + 1, C0 + cl, C0 + cl + 1)
                         self.wr('W', R0 + rl, C0 + cl, -acc)
 
-    def run_tri(self, l):
-        """one step of one level of the triangular inverse for the pairs [tri_p0, tri_p0 + tri_np): tiles of `u` blocks"""
-        u = 2 if l['tiles128'] else 1
-        mb, nbt = l['tri_mb'], self.nb // u
-        for pr in range(l['tri_p0'], l['tri_p0'] + l['tri_np']):
-            C0 = 2 * pr * mb
-            R0 = C0 + mb
-            for rl in range(mb):
-                for cl in range(mb):
-                    self.new_item()
-                    if R0 + rl >= nbt:
-                        continue
-                    r, c = (R0 + rl) * u, (C0 + cl) * u
-                    acc = np.zeros((TS * u, TS * u))
-                    if l['tri_w'] == 0:
-                        for kt in range(cl, mb):
-                            k = (C0 + kt) * u
-                            acc += self.rd('M', r, r + u, k, k + u) @ self.rd('W', k, k + u, c, c + u)
-                        self.wr('V', r, c, acc)
-                    else:
-                        for kt in range(0, rl + 1):
-                            k = (R0 + kt) * u
-                            acc += self.rd('W', r, r + u, k, k + u) @ self.rd('V', k, k + u, c, c + u)
-                        self.wr('W', r, c, -acc)
-
-    def run_psolve(self, l):
-        """rows from block row r_lo on: L[R, jt] = sum_{kt <= jt} A[R, kt] W_PP[jt, kt]^T on 128 x 128 tiles (2 x 2 blocks)"""
-        J, jt = l['J'], l['c_lo']
-        c0 = J + 2 * jt
-        for R in range(l['r_lo'] // 2, self.nb // 2):
-            self.new_item()
-            v = self.rd('M', 2 * R, 2 * R + 2, J, c0 + 2) @ self.rd('W', c0, c0 + 2, J, c0 + 2).T
-            self.wr('M', 2 * R, c0, v)
-
     def run(self, launches):
         for l in launches:
             self.begin_launch()
@@ -322,11 +226,80 @@ class Replay:
                 self.run_step(l)
             elif l['kind'] == 3:
                 self.run_trail(l)
-            elif l['kind'] == 5:
-                self.run_tri(l)
-            elif l['kind'] == 6:
-                self.run_psolve(l)
             self.run_jobs(l)
+            self.end_launch()
+
+    # ---- hosted panels (host_kernel, the out-of-place panel solve, the next-panel update): three launches per panel ----
+    def run_hosted(self, panels):
+        nb, q = self.nb, self.q
+        nan = np.full((TS, TS), np.nan)
+        for pi, p in enumerate(panels):
+            J, pe, ne = p['J'], p['pe'], p['ne']
+            # A: one chain workgroup factors and inverts the whole diagonal block; deferred updates beside it
+            self.begin_launch()
+            self.new_item()
+            m = pe - J
+            blk = np.zeros((m * TS, m * TS))
+            for r in range(m):
+                for c in range(r + 1):
+                    blk[r * TS:(r + 1) * TS, c * TS:(c + 1) * TS] = self.rd('M', J + r, J + r + 1, J + c, J + c + 1)
+            blk = np.tril(blk) + np.tril(blk, -1).T
+            Lb = np.linalg.cholesky(blk)
+            Wb = np.tril(np.linalg.inv(Lb))
+            self.wr('St', 0, 0, self.rd('St', 0, 1, 0, 1) + 1.0 * m)
+            for r in range(m):
+                for c in range(r + 1):
+                    self.wr('M', J + r, J + c, Lb[r * TS:(r + 1) * TS, c * TS:(c + 1) * TS])
+                    self.wr('W', J + r, J + c, Wb[r * TS:(r + 1) * TS, c * TS:(c + 1) * TS])
+                    if c < r:
+                        self.wr('V', J + r, J + c, nan)             # scratch of the block inverse
+                if (J + r) % 2 == 0 and J + r + 1 < nb:
+                    self.wr('W', J + r, J + r + 1, np.zeros((TS, TS)))
+            nblk = 0
+            for jb in p['jobs']:
+                assert jb['np'] * 4 == nb and 0 <= jb['k0'] < jb['k1'] <= J
+                ntile = 0
+                for cp in range(jb['cp0'], jb['cp0'] + jb['ncp']):
+                    assert cp > J // 4
+                    for R in range(cp, jb['np']):
+                        for h in range(2):
+                            self.new_item()
+                            ntile += 1
+                            for cc in range(4 * cp + 2 * h, 4 * cp + 2 * h + 2):
+                                for rr in range(4 * R, 4 * R + 4):
+                                    if rr < cc:
+                                        # above the diagonal: the kernel rewrites such a block too (rows 0 .. 127 of the second
+                                        # column tile excepted) -- nobody may read it
+                                        if not (h == 1 and rr < 4 * cp + 2):
+                                            self.wr('M', rr, cc, nan)
+                                        continue
+                                    t = self.rd('M', rr, rr + 1, cc, cc + 1) - \
+                                        self.rd('M', rr, rr + 1, jb['k0'], jb['k1']) @ self.rd('M', cc, cc + 1, jb['k0'], jb['k1']).T
+                                    self.wr('M', rr, cc, t)
+                assert jb['nblk'] == ntile * q
+                nblk += jb['nblk']
+            assert nblk == p['nhost']
+            self.end_launch()
+            if ne == pe:
+                break
+            # B: the rows below, L[R, panel] = X[R, panel] W_PP^T -- out of place from V; the first hosted panel sits in M and is
+            # solved in place, one launch per block column from the right
+            src = 'M' if pi == 0 else 'V'
+            for group in ([[jt] for jt in range(m - 1, -1, -1)] if pi == 0 else [list(range(m - 1, -1, -1))]):
+                self.begin_launch()
+                for jt in group:
+                    for R in range(pe, nb):
+                        self.new_item()
+                        v = self.rd(src, R, R + 1, J, J + jt + 1) @ self.rd('W', J + jt, J + jt + 1, J, J + jt + 1).T
+                        self.wr('M', R, J + jt, v)
+                self.end_launch()
+            # C: the next panel's columns receive this panel; its diagonal block stays in M, the rows below go to V
+            self.begin_launch()
+            for C in range(pe, ne):
+                for r in range(C, nb):
+                    self.new_item()
+                    t = self.rd('M', r, r + 1, C, C + 1) - self.rd('M', r, r + 1, J, pe) @ self.rd('M', C, C + 1, J, pe).T
+                    self.wr('M' if r < ne else 'V', r, C, t)
             self.end_launch()
 
     def check(self, inverse, ainv=True):
@@ -344,66 +317,6 @@ class Replay:
             for b in range(self.nb):     # whole diagonal tiles of A^-1 (the symv pass reads them whole)
                 s = slice(b * TS, (b + 1) * TS)
                 assert np.allclose(self.V[s, s], Ai[s, s], rtol=0, atol=1e-9)
-
-
-class DagReplay(Replay):
-    """The same plan as the task graph of the persistent launch (fill_sched.h: DagBuilder).  Segments are executed in
-    sequence order, each on a snapshot of the state before it; every block a segment reads must have been last written
-    by a segment in the transitive closure of its declared dependencies (or be initial data), and every block it writes
-    must have had all its earlier readers and its last writer in that closure: with these two properties ANY execution
-    that respects the per-(segment, component) counters gives the result of the sequential one."""
-
-    def run_dag(self, segs):
-        nseg = len(segs)
-        clo = []
-        for i, sg in enumerate(segs):
-            c = set()
-            for d, need in sg['deps']:
-                assert 0 <= d < i, 'dependencies point backwards in the sequence'
-                assert need == segs[d]['per_comp']
-                c.add(d)
-                c |= clo[d]
-            clo.append(c)
-        last_w = {}          # block -> segment
-        readers = {}         # block -> segments that read it since its last write
-        t_expect = 0
-        for i, sg in enumerate(segs):
-            assert sg['t0'] == t_expect and sg['ntasks'] == sg['per_comp'] * self.q
-            t_expect += sg['ntasks']
-            self.begin_launch()
-            if sg['kind'] == 1:
-                self.run_leaf(sg)
-            elif sg['kind'] == 2:
-                self.run_step(sg)
-            elif sg['kind'] == 3:
-                self.run_trail(sg)
-            elif sg['kind'] == 5:
-                self.run_tri(sg)
-            elif sg['kind'] == 6:
-                self.run_psolve(sg)
-            else:
-                self.run_jobs(sg)
-            self.end_launch()
-            nitems = self.item
-            if sg['kind'] == 3 and sg['tiles128'] and not (sg['t_count'] or sg['r_lo'] or sg['r_hi']):
-                # the kernel works on 128x128 tiles there (4 blocks, 3 on the diagonal, per task): same blocks, fewer tasks
-                nitems = sg['per_comp']
-            if sg['kind'] not in (4, 5) or (sg['kind'] == 4 and sg['type'] < 5):     # (a task of a block-inverse level may fall outside the matrix)
-                assert nitems == sg['per_comp'], (i, sg, nitems)
-            rset = {(b, r, c) for _, b, r, c in self.reads}
-            for key in rset:
-                w = last_w.get(key)
-                assert w is None or w == i or w in clo[i], 'segment %d reads %s written by %d: not a dependency' % (i, key, w)
-            for key in self.writes:
-                for o in [last_w.get(key)] + sorted(readers.get(key, ())):
-                    assert o is None or o == i or o in clo[i], 'segment %d writes %s last touched by %d: not a dependency' % (i, key, o)
-            for key in self.writes:
-                last_w[key] = i
-                readers[key] = set()
-            for key in rset:
-                if key not in self.writes:
-                    readers.setdefault(key, set()).add(i)
-        return max(sg['ndeps'] for sg in segs)
 
 
 CASES = [
@@ -457,41 +370,6 @@ def test_plan_without_inverse_replays_to_the_factor(dump_plan, nb, q, ob, kw):
     r.check(inverse=False)
 
 
-WIDE_CASES = [
-    (64, 8, 4, dict(fill_wide=1, fill_leaf=496, fill_step=496)),      # the headline size, eight components: one wide tile per CU
-    (64, 8, 4, dict(fill_wide=1, fill_leaf=992, fill_step=992)),
-    (64, 1, 4, dict(fill_wide=1)),
-    (64, 2, 4, dict(fill_wide=1, fill_leaf=496, fill_step=496, far_rides=0)),
-    (32, 6, 4, dict(fill_wide=1, fill_leaf=496, fill_step=496)),
-    (18, 1, 4, dict(fill_wide=1)),                                    # a short last panel
-    (10, 3, 4, dict(fill_wide=1, fill_leaf=40, fill_step=24)),
-    (24, 2, 8, dict(fill_wide=1)),
-    (12, 1, 2, dict(fill_wide=1)),
-    (14, 2, 6, dict(fill_wide=1)),
-    (16, 1, 3, dict(fill_wide=1)),                                    # odd panels: the jobs stay 128 x 64
-]
-
-
-@pytest.mark.parametrize('nb,q,ob,kw', WIDE_CASES)
-@pytest.mark.parametrize('mode', ['factor', 'inverse', 'inverse_and_ainv'])
-def test_plans_with_128x128_filler_tiles(dump_plan, nb, q, ob, kw, mode):
-    """FillJob::wide: the far columns of the trailing update and the rank-(64 ob) updates of the inverse as column pairs"""
-    prog = 0 if mode == 'factor' else 1
-    if prog and ob & (ob - 1):
-        pytest.skip('the progressive inverse needs a power-of-two panel (plan_params)')
-    launches = dump_plan(nb, q, ob, progressive=prog, with_dupd=1 if mode == 'inverse_and_ainv' else 0, **kw)
-    big = [jb for l in launches for jb in l['jobs'] if jb['type'] in (1, 3)]
-    assert all(bool(jb.get('wide')) == (ob % 2 == 0) for jb in big)
-    assert not any(jb.get('wide') for l in launches for jb in l['jobs'] if jb['type'] not in (1, 3))
-    cap = max(kw.get('fill_leaf', 248), kw.get('fill_step', 248))
-    for l in launches:
-        if l['kind'] in (1, 2):
-            assert sum(jb['nblk'] * (2 if jb.get('wide') else 1) for jb in l['jobs']) <= cap
-    r = Replay(nb, q, seed=5 * nb + q)
-    r.run(launches)
-    r.check(inverse=prog == 1, ainv=mode == 'inverse_and_ainv')
-
-
 def test_filler_capacity_is_respected(dump_plan):
     for q in (1, 2, 8):
         for l in dump_plan(64, q, 4, progressive=1):
@@ -500,112 +378,41 @@ def test_filler_capacity_is_respected(dump_plan):
                 assert len(l['jobs']) <= 6
 
 
-@pytest.mark.parametrize('nb,q,ob,kw', CASES + [(14, 2, 6, {}), (16, 1, 3, {})])
-@pytest.mark.parametrize('progressive', [0, 1])
-def test_task_graph_dependencies_cover_every_block_hazard(dump_plan, nb, q, ob, kw, progressive):
-    if progressive and (ob & (ob - 1)):
-        pytest.skip('the progressive inverse needs a power-of-two panel')
-    launches, segs = dump_plan(nb, q, ob, progressive=progressive, dag=1, **kw)
-    r = DagReplay(nb, q, seed=5 * nb + q)
-    maxdep = r.run_dag(segs)
-    assert maxdep <= 16
-    r.check(inverse=bool(progressive))
-    # the graph holds exactly the work of the launch list
-    assert sum(sg['ntasks'] for sg in segs if sg['kind'] == 4) == sum(jb['nblk'] for l in launches for jb in l['jobs'])
+HOSTED = [(64, 8, 0, 2), (64, 8, 0, 1), (64, 8, 0, 4), (64, 1, 0, 2), (16, 4, 0, 2), (32, 6, 0, 3), (8, 1, 0, 2), (12, 2, 0, 2),
+          (64, 8, 32, 2), (64, 4, 48, 2), (32, 6, 16, 1), (16, 2, 8, 2), (16, 2, 12, 2), (72, 2, 36, 16)]
 
 
-def test_task_graph_mutations_are_caught(dump_plan):
-    """dropping any single declared dependency of the headline graph must trip the hazard check (the lists are minimal)"""
-    launches, segs = dump_plan(16, 2, 4, progressive=1, dag=1)
-    caught = total = 0
-    for i, sg in enumerate(segs):
-        for j in range(sg['ndeps']):
-            import copy
-            mut = copy.deepcopy(segs)
-            del mut[i]['deps'][j]
-            mut[i]['ndeps'] -= 1
-            total += 1
-            try:
-                DagReplay(16, 2, seed=1).run_dag(mut)
-            except AssertionError:
-                caught += 1
-    assert total > 20 and caught == total, (caught, total)
-
-
-@pytest.mark.parametrize('nb,q,ob,kw', [(64, 8, 4, {}), (64, 1, 4, {}), (64, 2, 4, {}), (16, 4, 4, {}), (32, 6, 4, {}), (18, 1, 4, {}),
-                                        (10, 3, 4, {}), (6, 1, 4, {}), (4, 1, 4, {}), (2, 1, 4, {}), (24, 2, 8, {}), (20, 1, 8, {}),
-                                        (12, 1, 2, {}), (14, 2, 6, {}), (16, 1, 3, {}), (32, 1, 4, dict(syrk_small=0)),
-                                        (32, 3, 2, dict(syrk_small=0)), (64, 4, 4, dict(syrk_small=100))])
-def test_interleaved_order_for_the_persistent_launch(dump_plan, nb, q, ob, kw):
-    """near / far trailing updates, the far part in chunks that alternate with the next panel's chain (Planner::
-    run_interleaved): valid as a launch list, and as a task graph with the derived dependencies"""
-    launches, segs = dump_plan(nb, q, ob, progressive=0, dag=1, interleaved=1, **kw)
+@pytest.mark.parametrize('nb,q,host_from,defer', HOSTED)
+def test_hosted_panels_replay_to_the_factor(dump_plan, nb, q, host_from, defer):
+    """lcgp_sched.hosted: the launch-by-launch plan up to block column `host_from` (0: none), then per panel the launch that
+    factors its whole diagonal block beside deferred trailing updates, the panel solve and the next-panel update"""
+    launches, panels = dump_plan(nb, q, 4, progressive=0, host_from=host_from, defer=defer)
+    assert len(panels) == (nb - host_from) // 4
+    assert all(l['pe'] <= host_from for l in launches)
     r = Replay(nb, q, seed=7 * nb + q)
     r.run(launches)
+    r.run_hosted(panels)
     r.check(inverse=False)
-    r = DagReplay(nb, q, seed=7 * nb + q)
-    assert r.run_dag(segs) <= 16
-    r.check(inverse=False)
-    # a chain launch never waits for a far chunk of the update before it: that is the point of the order
-    kinds = {i: sg for i, sg in enumerate(segs)}
-    for i, sg in enumerate(segs):
-        if sg['kind'] in (1, 2):
-            for d, _ in sg['deps']:
-                assert not (kinds[d]['kind'] == 3 and kinds[d]['c_lo'] > sg['pe']), (i, sg, kinds[d])
-    # ... and the chain part of a step never waits for the bulk part of another
-    for i, sg in enumerate(segs):
-        if sg['kind'] == 2 and sg['has_special']:
-            for d, _ in sg['deps']:
-                assert not (kinds[d]['kind'] == 2 and kinds[d]['trmm_r0'] > kinds[d]['c'] + 1), (i, sg, kinds[d])
+    # every column panel receives every finished panel exactly once (the deferred jobs + the next-panel updates)
+    np_ = nb // 4
+    seen = {c: [] for c in range(np_)}
+    for p in panels:
+        for jb in p['jobs']:
+            for c in range(jb['cp0'], jb['cp0'] + jb['ncp']):
+                seen[c] += list(range(jb['k0'] // 4, jb['k1'] // 4))
+        if p['ne'] > p['pe']:
+            seen[p['pe'] // 4].append(p['J'] // 4)
+    for c in range(host_from // 4 + 1, np_):
+        assert sorted(seen[c]) == list(range(host_from // 4, c)), c
 
 
-@pytest.mark.parametrize('nb,q,ob,kw', [(64, 8, 4, {}), (64, 1, 4, {}), (64, 2, 4, {}), (16, 4, 4, {}), (32, 6, 4, {}), (18, 1, 4, {}),
-                                        (10, 3, 4, {}), (6, 1, 4, {}), (4, 1, 4, {}), (2, 1, 4, {}), (24, 2, 8, {}), (20, 1, 8, {}),
-                                        (12, 1, 2, {}), (14, 2, 6, {}), (16, 1, 3, {}), (32, 2, 4, dict(trtri_all_small=1)),
-                                        (22, 3, 4, dict(trtri_all_small=1)), (64, 4, 4, dict(syrk_small=100))])
-def test_interleaved_order_with_the_triangular_inverse(dump_plan, nb, q, ob, kw):
-    """the factorisation AND W = L^-1 as one sequence: the early levels of the inverse ride on the chain-bound end of the
-    factorisation, the rest follows; replayed as a launch list and as a task graph"""
-    launches, segs = dump_plan(nb, q, ob, progressive=0, dag=1, interleaved=1, with_trtri=1, **kw)
-    assert any(l['kind'] == 5 for l in launches) or nb < 2
-    r = Replay(nb, q, seed=11 * nb + q)
+def test_hosted_replay_catches_a_missing_contribution(dump_plan):
+    launches, panels = dump_plan(32, 2, 4, progressive=0, host_from=0, defer=2)
+    victim = next(p for p in panels if p['jobs'])
+    victim['nhost'] -= victim['jobs'][-1]['nblk']
+    victim['jobs'].pop()
+    r = Replay(32, 2, seed=1)
     r.run(launches)
-    r.check(inverse=True, ainv=False)
-    r = DagReplay(nb, q, seed=11 * nb + q)
-    assert r.run_dag(segs) <= 16
-    r.check(inverse=True, ainv=False)
-    # no step of the factorisation waits for a unit of the inverse
-    for i, sg in enumerate(segs):
-        if sg['kind'] in (1, 2, 3):
-            assert all(segs[d]['kind'] != 5 for d, _ in sg['deps']), (i, sg)
-
-
-def check_runs(segs, runs, q):
-    """the sequence the persistent kernel takes its tasks in: every segment's tasks exactly once, in order, and every run
-    behind ALL runs of everything its segment depends on (so that a task that has been taken only ever waits for tasks
-    before it in the sequence: no deadlock, whatever the number of resident workgroups)"""
-    pos_last = {}
-    nxt = [0] * len(segs)
-    t0 = 0
-    for i, r in enumerate(runs):
-        assert r['t0'] == t0 and r['n'] > 0
-        t0 += r['n']
-        sg = segs[r['seg']]
-        assert r['b0'] == nxt[r['seg']], 'runs of a segment in task order'
-        nxt[r['seg']] += r['n']
-        for d, _ in sg['deps']:
-            assert nxt[d] == segs[d]['ntasks'], 'run %d of segment %d starts before segment %d has been taken whole' % (i, r['seg'], d)
-    assert all(nxt[i] == sg['ntasks'] for i, sg in enumerate(segs))
-    assert t0 == sum(sg['ntasks'] for sg in segs)
-
-
-@pytest.mark.parametrize('nb,q,ob,kw', [(64, 8, 4, {}), (64, 1, 4, {}), (64, 2, 4, {}), (16, 4, 4, {}), (32, 6, 4, {}), (18, 1, 4, {}),
-                                        (10, 3, 4, {}), (2, 1, 4, {}), (24, 2, 8, {}), (12, 1, 2, {}), (14, 2, 6, {}),
-                                        (32, 2, 4, dict(trtri_all_small=1))])
-@pytest.mark.parametrize('mode', ['launch order', 'interleaved', 'interleaved with inverse'])
-def test_scheduled_sequence_is_a_valid_order_of_the_graph(dump_plan, nb, q, ob, kw, mode):
-    extra = dict(interleaved=0) if mode == 'launch order' else dict(interleaved=1, with_trtri=int(mode.endswith('inverse')))
-    if mode == 'launch order':
-        kw = {k: v for k, v in kw.items() if k != 'trtri_all_small'}
-    launches, segs = dump_plan(nb, q, ob, progressive=int(mode == 'launch order' and (ob & (ob - 1)) == 0), dag=1, **extra, **kw)
-    check_runs(segs, dump_plan.last_runs, q)
+    r.run_hosted(panels)
+    with pytest.raises(AssertionError):
+        r.check(inverse=False)

@@ -81,8 +81,11 @@ class _RankShares:
         self.device = None
         q = int(m.q)
         self.ks = [list(range(r, q, world)) for r in range(world)]
-        self.engines = [HotPathEngine(m.x.numpy(), m.y.numpy(), None, len(ks), 'float64', 'cuda:0', comp_ids=ks, q_total=q)
-                        for ks in self.ks]
+        base = m._get_engine()          # resident inputs of the path as the model hands them to an engine (full: x, y; replicated:
+                                        # the unique inputs, sqrt(r) o ybar and sr = sqrt(r))
+        xs, Ys = base.x.cpu().numpy(), base.Y.cpu().numpy()
+        sr = None if base.sr is None else base.sr.cpu().numpy()
+        self.engines = [HotPathEngine(xs, Ys, sr, len(ks), 'float64', 'cuda:0', comp_ids=ks, q_total=q) for ks in self.ks]
 
     def evaluate_partial(self, theta_rows, guard=0.0):
         total = None
@@ -104,6 +107,19 @@ def test_cfg3_rank_shares_sum_to_the_golden(world):
     m._engine = _RankShares(m, world)
     assert [e.q_local for e in m._engine.engines] == [8 // world] * world
     _check_points(m, 'cfg3_n4096', NLL_TOL, GRAD_TOL)
+
+
+def test_cfg5_rank_shares_sum_to_the_golden():
+    """configs[4] as BASELINE.json states it (4 GPUs): q = 6 components over 4 ranks -> UNEVEN shares 2 / 2 / 1 / 1 of the
+    replicated path, each on its own real engine (that rank's q_local: thresholds, progressive inverse), summed like the
+    all-reduce, against the cfg5 golden (lcgp.py:554-630; fan-out lcgp.py:792-794)."""
+    x, y, cfg = synth.make_config(5)
+    m = LCGP(y=y, x=x, q=cfg['q'], submethod='rep')
+    m._get_engine()
+    m._engine = _RankShares(m, 4)
+    assert [e.q_local for e in m._engine.engines] == [2, 2, 1, 1]
+    assert [e.sr is not None for e in m._engine.engines] == [True] * 4
+    _check_points(m, 'cfg5_rep_n2048x5', NLL_TOL, GRAD_TOL)
 
 
 def test_ragged_n4000_against_the_golden():

@@ -229,14 +229,8 @@ def test_wide_tile_schedules_agree_at_medium_size():
                        dict(progressive_tiles=0), dict(progressive_tiles=1 << 30), dict(progressive_tiles=1 << 30, syrk_small_tiles=16),
                        dict(progressive_tiles=1 << 30, progressive_far=0, syrk_small_tiles=16),
                        dict(progressive_tiles=1 << 30, fill_leaf=40, fill_step=56), dict(progressive_tiles=1 << 30, outer_blocks=8),
-                       # 128x128 filler tiles (lcgp_sched.fill_wide): trailing update alone, and the inverse behind the chain
-                       dict(fill_wide=1, syrk_small_tiles=16), dict(fill_wide=1, syrk_small_tiles=16, fill_leaf=40, fill_step=56),
-                       dict(fill_wide=1, syrk_small_tiles=16, fill_leaf=992, fill_step=992),
-                       dict(fill_wide=1, progressive_tiles=0, syrk_small_tiles=1, outer_blocks=2),
-                       dict(fill_wide=1, progressive_tiles=1 << 30), dict(fill_wide=1, progressive_tiles=1 << 30, fill_leaf=30, fill_step=18),
-                       dict(fill_wide=1, progressive_tiles=1 << 30, progressive_lauum=0, outer_blocks=8),
-                       dict(fill_wide=1, progressive_tiles=1 << 30, progressive_far=0, syrk_small_tiles=16),
-                       dict(fill_wide=1, outer_blocks=3)):      # odd panels: the jobs stay 128x64
+                       # hosted panels (n pads to 1536 = 6 panels of 256 columns)
+                       dict(hosted=1), dict(hosted=1, hosted_defer=1), dict(hosted=1, hosted_defer=3)):
             eng.sched = _sched(**fields)
             v, g = m.loss_and_grad(u)
             assert abs(v - ref_v) <= 1e-11 * abs(ref_v), fields
@@ -274,9 +268,7 @@ def test_progressive_inverse_with_jobs_split_over_launches():
         ref_w, ref_a, ref_z = np.tril(eng.fetch_matrix(1, 5)), np.tril(eng.fetch_matrix(2, 5)), eng.fetch_vector(1, 5)
         for fields in (dict(progressive_tiles=1 << 30), dict(progressive_tiles=1 << 30, fill_leaf=30, fill_step=18),
                        dict(progressive_tiles=1 << 30, fill_leaf=6, fill_step=6), dict(progressive_tiles=1 << 30, progressive_far=0),
-                       dict(progressive_tiles=1 << 30, progressive_lauum=0), dict(progressive_tiles=1 << 30, progressive_lauum=0, fill_leaf=30, fill_step=18),
-                       dict(progressive_tiles=1 << 30, fill_wide=1), dict(progressive_tiles=1 << 30, fill_wide=1, fill_leaf=30, fill_step=18),
-                       dict(progressive_tiles=1 << 30, fill_wide=1, progressive_lauum=0, fill_leaf=992, fill_step=992)):
+                       dict(progressive_tiles=1 << 30, progressive_lauum=0), dict(progressive_tiles=1 << 30, progressive_lauum=0, fill_leaf=30, fill_step=18)):
             eng.sched = _sched(**fields)
             v, g = m.loss_and_grad(u)
             assert abs(v - ref_v) <= 1e-11 * abs(ref_v), fields

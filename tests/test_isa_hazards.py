@@ -40,15 +40,16 @@ def test_product_kernels_have_no_dpp_hazard():
     assert chk.main() == 0
 
 
-# ---- barriers of the persistent kernel: the LDS write of the task id must be complete before the loop-header barrier ----
+# ---- barriers behind a loop's back edge: an LDS write of the previous iteration must be complete before the barrier ----
 spec2 = importlib.util.spec_from_file_location('check_barrier_waits', os.path.join(ROOT, 'tools', 'check_barrier_waits.py'))
 cbw = importlib.util.module_from_spec(spec2)
 spec2.loader.exec_module(cbw)
 
 
 def test_barrier_checker_flags_the_pattern_hipcc_emitted():
-    """what ROCm 7.2 made of dag_kernel's loop before the wait was written out: the task id is stored to LDS at the end of
-    an iteration and the loop header is a bare s_barrier followed by the other waves' ds_read"""
+    """what ROCm 7.2 made of the loop of round 4's persistent kernel (docs/experiments/) before the wait was written out: a
+    value is stored to LDS at the end of an iteration and the loop header is a bare s_barrier followed by the other waves'
+    ds_read"""
     bad = """
 .LBB18_6:
 	ds_write_b32 v228, v2
@@ -76,5 +77,5 @@ def test_barrier_checker_flags_the_pattern_hipcc_emitted():
 
 
 @pytest.mark.skipif(shutil.which('hipcc') is None, reason='needs hipcc')
-def test_persistent_kernel_barriers_wait_for_lds_writes():
+def test_every_kernel_barrier_waits_for_lds_writes():
     assert cbw.main() == 0

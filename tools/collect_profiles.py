@@ -42,9 +42,7 @@ def main():
                  ('bench_q1.json', 'bench_q1.json'), ('bench_gloo2.json', 'bench_gloo2_one_gpu.json'),
                  ('host_overhead.txt', 'host_overhead.txt'), ('timeline_q1_progressive.txt', 'timeline_q1_progressive.txt'),
                  ('timeline_q1_classic.txt', 'timeline_q1_classic.txt'), ('fit_wallclock.txt', 'fit_wallclock.txt'),
-                 ('timeline_q8.txt', 'timeline_q8.txt'), ('dag_ab.txt', 'dag_ab.txt'), ('coherence_test.txt', 'coherence_test.txt'),
-                 ('dag_trace_q8_potrf.txt', 'dag_trace_q8_potrf.txt'), ('dag_trace_q8_with_inverse.txt', 'dag_trace_q8_with_inverse.txt'),
-                 ('dag_trace_q1_potrf.txt', 'dag_trace_q1_potrf.txt')):
+                 ('timeline_q8.txt', 'timeline_q8.txt')):
         if not os.path.exists(os.path.join(src, a)):
             continue
         shutil.copy(os.path.join(src, a), os.path.join(dst, '%s_%s' % (pre, b)))

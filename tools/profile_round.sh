@@ -4,13 +4,13 @@
 # rocprofv3 passes: --kernel-trace --stats on its own; every --pmc pass on its own with --kernel-trace only
 # (never together with the hip/hsa/memory trace domains); the program itself follows `--`.
 set -u
-TAG=${1:-r04}
+TAG=${1:-r05}
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$ROOT/gpurun_out/$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 step() { echo "[profile_round] $*"; }
-PART=${2:-all}        # A = bench lines + counter passes, B = traces, persistent-launch A/B, fits (a gpurun call is limited to 20 minutes)
+PART=${2:-all}        # A = bench lines + counter passes, B = traces, fits (a gpurun call is limited to 20 minutes)
 if [ "$PART" != B ]; then
 
 step "bench (default: N=1, headline configuration)"
@@ -22,16 +22,6 @@ for q in 4 2 1; do python3 $ROOT/bench.py --q $q --steps 12 --warmup 3 --no-cpu-
 step "host overhead (caller-owned plan vs plan per call; q = 8 and one rank's share)"
 python3 $ROOT/tools/host_overhead.py 3 > $OUT/host_overhead.txt 2>&1 || exit 1
 python3 $ROOT/tools/host_overhead.py 3 1 >> $OUT/host_overhead.txt 2>&1 || exit 1
-step "the persistent factorisation launch against launch by launch (same process, same box), q = 8, 4, 2, 1"
-for q in 8 4 2 1; do python3 $ROOT/tools/ab.py --q $q --reps 3 --steps 10 "launch by launch:dag=0" "persistent, launch order:dag=1" "persistent, scheduled, with L^-1:dag=2" "persistent, scheduled, factorisation only:dag=2,dag_flags=256" >> $OUT/dag_ab.txt 2>&1 || exit 1; done
-if [ -f $ROOT/lcgp_amd/liblcgp_hip_trace.so ]; then
-  step "task trace of the persistent launch (stamped build), q = 8 and q = 1"
-  LCGP_HIP_LIB=$ROOT/lcgp_amd/liblcgp_hip_trace.so python3 $ROOT/tools/dag_trace.py --q 8 --dag 2 --bucket 250 --chain 24 dag_flags=256 > $OUT/dag_trace_q8_potrf.txt 2>&1 || exit 1
-  LCGP_HIP_LIB=$ROOT/lcgp_amd/liblcgp_hip_trace.so python3 $ROOT/tools/dag_trace.py --q 8 --dag 2 --bucket 250 > $OUT/dag_trace_q8_with_inverse.txt 2>&1 || exit 1
-  LCGP_HIP_LIB=$ROOT/lcgp_amd/liblcgp_hip_trace.so python3 $ROOT/tools/dag_trace.py --q 1 --dag 2 --bucket 250 --chain 24 dag_flags=256 > $OUT/dag_trace_q1_potrf.txt 2>&1 || exit 1
-fi
-step "cross-XCD hand-off forms (standalone measurement)"
-[ -x $ROOT/tools/coherence_test ] && $ROOT/tools/coherence_test > $OUT/coherence_test.txt 2>&1
 step "kernel stats of the bench command"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $ROOT/bench.py --steps 10 --warmup 2 --no-cpu-baseline > $OUT/stats.log 2>&1 || exit 1
 step "PMC: VALU / occupancy counters (cfg3, 3 evaluations)"
