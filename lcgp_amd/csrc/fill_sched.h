@@ -520,14 +520,22 @@ class Planner {
 // share: column c is visited by A(P) when (c - 1 - P) is a multiple of `defer` -- which makes the visit of A(c - 1), the
 // last chance before the column's own chain, a regular one.  tests/test_fill_sched.py replays the plan on numpy matrices.
 // ---------------------------------------------------------------------------------------------------
-constexpr int HOST_NJ = 16;
+constexpr int HOST_NJ = 24;
+
+enum HostJobType { HJ_UPDATE = 0, HJ_TRI_T = 1 };
 
 struct HostJob {
-    int cp0, ncp;        // column panels cp0 .. cp0 + ncp - 1 (256 columns = two 128-column tiles each)
+    int type;
+    // HJ_UPDATE: deferred trailing update of the column panels cp0 .. cp0 + ncp - 1 (256 columns = two 128-column tiles each;
+    // column panel c has the 256-row blocks c .. np - 1):  M[R, c] -= sum_{k0 <= k < k1} L[R, k] L[c, k]^T
+    // HJ_TRI_T:  one K chunk of the top-level product of the triangular inverse, T = L21 W11 (into V), for the 128-column tile
+    // `ct` and the 256-row blocks cp0 .. cp0 + ncp - 1:  V[R, ct] (+)= sum_{k0 <= k < k1} L[R, k] W[k, ct]   (`first`: written)
+    int cp0, ncp;
     int k0, k1;          // K range in 64-blocks
-    int np;              // panels per side: column panel c has the 256-row blocks c .. np - 1
-    int nblk;            // blocks = tiles x components (component = fastest index); tiles column panel by column panel,
-                         // row block by row block, the two column tiles of a row block adjacent
+    int np;              // panels per side
+    int ct, first;
+    int nblk;            // blocks = tiles x components (component = fastest index); HJ_UPDATE: column panel by column panel,
+                         // row block by row block, the two column tiles of a row block adjacent; HJ_TRI_T: row block by row block
 };
 
 inline long host_job_tiles(int cp0, int ncp, int np) {
@@ -538,7 +546,8 @@ inline long host_job_tiles(int cp0, int ncp, int np) {
 
 struct HostPanel {
     HostPanel() { memset((void*)this, 0, sizeof(*this)); }
-    int J, pe, ne;       // the panel's block columns [J, pe), the next panel's [pe, ne)  (ne = pe: the last panel)
+    int J, pe, ne;       // the panel's block columns [J, pe), the next panel's [pe, ne)  (ne = pe: the last panel);
+                         // J < 0: no panel at all -- a launch of hosted tiles only (what the panels could not carry)
     int njobs;
     int nhost;           // blocks of all jobs
     HostJob job[HOST_NJ];
@@ -553,15 +562,82 @@ class HostPlanner {
     bool failed = false;
     static bool applicable(int nb) { return nb >= 8 && nb % 4 == 0; }
 
+    // The top-level product of the triangular inverse rides on the hosted panels: T = L[tri_h.., 0..tri_h) W[0..tri_h, 0..tri_h)
+    // (tri_h = 4 p0 block columns: everything it reads is final when the first hosted panel starts -- the caller has formed
+    // W11 = L11^-1 in front of it).  Column strips of 128 x K chunks of at most `chunk` 64-blocks, walked from the last block row
+    // of W11 upwards; a launch takes chunks while its workgroups besides the chain are estimated to finish with the chain.
+    int tri_h = 0;
+    int slots = 248;             // compute units besides the chain workgroups
+    double chain_us = 165.0;     // the chain workgroup of a panel (measured: 157 alone, 165-177 beside a full chip)
+    double unit_us = 36.0;       // a 256 x 128 tile per 128 of K (measured: 34 alone, 37 beside a full chip)
+    double tile_us = 8.0;        // ... plus its two ends
+    int chunk = 8;
+
     void run() {
         const int ob = 4, np = nb / ob;
         std::vector<int> applied(np, p0);         // panels [0, applied[c]) have been applied to column panel c
+        // K chunks of the strips of T, in the order they may run: chunk index first (a strip's chunks must follow each other
+        // in DIFFERENT launches), strips left to right (longest K first)
+        struct Chunk { int ct, k0, k1, idx; };
+        std::vector<Chunk> chunks;
+        if (tri_h > 0) {
+            const int nst = tri_h / 2;
+            for (int idx = 0;; ++idx) {
+                bool any = false;
+                for (int ct = 0; ct < nst; ++ct) {
+                    const int len = tri_h - 2 * ct;                       // the strip's K range [2 ct, tri_h) in 64-blocks
+                    const int nch = (len + chunk - 1) / chunk;
+                    if (idx >= nch) continue;
+                    // even split in multiples of two blocks, the longer chunks first (from the bottom of W11 upwards)
+                    const int pairs = len / 2, base = pairs / nch, extra = pairs % nch;
+                    int hi = tri_h;
+                    for (int i = 0; i < idx; ++i) hi -= 2 * (base + (i < extra ? 1 : 0));
+                    const int lo = hi - 2 * (base + (idx < extra ? 1 : 0));
+                    chunks.push_back({ct, lo, hi, idx});
+                    any = true;
+                }
+                if (!any) break;
+            }
+        }
+        size_t next_chunk = 0;
+        auto tile_cost = [&](int kblocks) { return tile_us + unit_us * kblocks / 2.0; };
+        auto take_chunks = [&](HostPanel& hp, double budget) {
+            // (CU-microseconds left beside the panel's own jobs)
+            std::vector<int> strips;
+            const int nr = np - p0;
+            while (next_chunk < chunks.size() && hp.njobs < HOST_NJ) {
+                const Chunk& c = chunks[next_chunk];
+                bool clash = false;
+                for (int s : strips) clash = clash || s == c.ct;
+                const double cost = (double)nr * q * tile_cost(c.k1 - c.k0);
+                if (clash || cost > budget) break;
+                HostJob& j = hp.job[hp.njobs++];
+                j.type = HJ_TRI_T; j.cp0 = p0; j.ncp = nr; j.k0 = c.k0; j.k1 = c.k1; j.np = np; j.ct = c.ct; j.first = c.idx == 0 ? 1 : 0;
+                budget -= cost;
+                strips.push_back(c.ct);
+                ++next_chunk;
+            }
+        };
+        auto finish = [&](HostPanel& hp) {
+            // longest K first
+            for (int i = 1; i < hp.njobs; ++i)
+                for (int j = i; j > 0 && hp.job[j].k1 - hp.job[j].k0 > hp.job[j - 1].k1 - hp.job[j - 1].k0; --j)
+                    std::swap(hp.job[j], hp.job[j - 1]);
+            for (int i = 0; i < hp.njobs; ++i) {
+                HostJob& j = hp.job[i];
+                j.nblk = (int)((j.type == HJ_TRI_T ? (long)j.ncp : host_job_tiles(j.cp0, j.ncp, np)) * q);
+                hp.nhost += j.nblk;
+            }
+            panels.push_back(hp);
+        };
         for (int P = p0; P < np; ++P) {
             HostPanel hp;
             hp.J = P * ob; hp.pe = hp.J + ob; hp.ne = P + 1 < np ? hp.pe + ob : hp.pe;
+            double own = 0.0;
             for (int c = P + 1; c < np; ++c) {
                 if (applied[c] >= P) continue;
                 if (c != P + 1 && (c - 1 - P) % defer != 0) continue;
+                own += 2.0 * (np - c) * q * tile_cost((P - applied[c]) * ob);
                 // merge with the previous job when it is the column panel next to it with the same K range
                 if (hp.njobs > 0) {
                     HostJob& pj = hp.job[hp.njobs - 1];
@@ -571,22 +647,25 @@ class HostPlanner {
                         continue;
                     }
                 }
-                if (hp.njobs >= HOST_NJ) continue;        // (stays pending: a later launch takes it with a longer K)
+                if (hp.njobs >= HOST_NJ) { own -= 2.0 * (np - c) * q * tile_cost((P - applied[c]) * ob); continue; }
+                                                                   // (stays pending: a later launch takes it with a longer K)
                 HostJob& j = hp.job[hp.njobs++];
-                j.cp0 = c; j.ncp = 1; j.k0 = applied[c] * ob; j.k1 = P * ob; j.np = np;
+                j.type = HJ_UPDATE; j.cp0 = c; j.ncp = 1; j.k0 = applied[c] * ob; j.k1 = P * ob; j.np = np;
                 applied[c] = P;
             }
             if (P + 1 < np && applied[P + 1] != P) { failed = true; return; }
-            // longest K first
-            for (int i = 1; i < hp.njobs; ++i)
-                for (int j = i; j > 0 && hp.job[j].k1 - hp.job[j].k0 > hp.job[j - 1].k1 - hp.job[j - 1].k0; --j)
-                    std::swap(hp.job[j], hp.job[j - 1]);
-            for (int i = 0; i < hp.njobs; ++i) {
-                hp.job[i].nblk = (int)(host_job_tiles(hp.job[i].cp0, hp.job[i].ncp, np) * q);
-                hp.nhost += hp.job[i].nblk;
-            }
-            panels.push_back(hp);
+            take_chunks(hp, (double)slots * chain_us - own);
+            finish(hp);
             if (P + 1 < np) applied[P + 1] = P + 1;      // C(P)
+        }
+        // what the panels could not carry: launches of tiles only, a strip's chunks still one launch apart
+        int guard = 0;
+        while (next_chunk < chunks.size()) {
+            HostPanel hp;
+            hp.J = hp.pe = hp.ne = -1;
+            take_chunks(hp, 1e30);
+            if (hp.njobs == 0 || ++guard > 4 * nb) { failed = true; return; }
+            finish(hp);
         }
     }
 

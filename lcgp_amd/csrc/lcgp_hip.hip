@@ -1585,6 +1585,7 @@ using lcgp_fill::HOST_NJ;
 struct HostArgs {
     void* M; void* W; void* V; size_t mat; int npad, nb, q;
     int J, pe;                      // the panel's block columns [J, pe)
+    int nchain;                     // chain workgroups in front of the tiles: q, or 0 for a launch of hosted tiles only
     double* logdet; int* info;
     int njobs;
     HostJob job[HOST_NJ];
@@ -1594,54 +1595,41 @@ constexpr int HOST_TM = 256, HOST_TN = 128, HOST_NT = 512;
 template <typename T>
 constexpr int host_tile_lds() { return 2 * KT * (HOST_TM + 16 + HOST_TN + 16) * (int)sizeof(T); }
 
-template <typename T>
-__device__ __forceinline__ void host_tile_body(const HostArgs& a, int b, unsigned char* lds) {
+// One 256 x 128 tile on eight waves (64 x 64 per wave):  C (-)= sum over nst stages of 16 k  A(256 x k) B(128 x k)^T-like,
+// A with k contiguous (MK), B in either layout; `preload`: the accumulators start from the C tile (else from zero);
+// a wave that is not `live` only helps staging; stages [0, dead) of a live wave add exact zeros (a triangular B) and are skipped.
+template <typename T, int LB, bool NEG>
+__device__ __forceinline__ void host_tile_core(const T* __restrict__ A0, int ldA, const T* __restrict__ B0, int ldB,
+                                               T* __restrict__ Ct, int ldC, int nst, bool preload, bool live, int dead,
+                                               int wm0, int wn0, int tid, int lane, unsigned char* lds) {
     constexpr int LDA = HOST_TM + 16, LDB = HOST_TN + 16;
     constexpr int EA = HOST_TM * KT / HOST_NT, EB = HOST_TN * KT / HOST_NT;
-    int ji = 0;
-    while (ji + 1 < a.njobs && b >= a.job[ji].nblk) { b -= a.job[ji].nblk; ++ji; }
-    const HostJob jb = a.job[ji];
-    const int k = b % a.q;
-    int t = b / a.q, cp = jb.cp0;
-    while (t >= 2 * (jb.np - cp)) { t -= 2 * (jb.np - cp); ++cp; }
-    const int R = cp + (t >> 1), ct = 2 * cp + (t & 1);            // 256-row block, 128-column tile
-    const int ld = a.npad;
-    T* Mk = (T*)a.M + (size_t)k * a.mat;
-    const T* A0 = Mk + (size_t)R * HOST_TM * ld + (size_t)jb.k0 * TS;
-    const T* B0 = Mk + (size_t)ct * HOST_TN * ld + (size_t)jb.k0 * TS;
-    T* Ct = Mk + (size_t)R * HOST_TM * ld + (size_t)ct * HOST_TN;
-    const int nst = (jb.k1 - jb.k0) * (TS / KT);
     T* As = (T*)lds;                    // [2][KT * LDA]
     T* Bs = As + 2 * KT * LDA;          // [2][KT * LDB]
-    const int tid = body_tid(), lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm0 = (wave >> 1) * 64, wn0 = (wave & 1) * 64;
-    // the second column tile of the panel's own row block: its rows 0 .. 127 lie above the diagonal (never read by anyone)
-    const bool live = !(R == cp && (t & 1) && wm0 < 128);
     typedef typename Mfma<T>::acc_t acc_t;
     acc_t acc[4][4];
-    if (live) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
+        for (int j = 0; j < 4; ++j)
 #pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    acc[i][j][e] = Ct[(size_t)(wm0 + i * 16 + Mfma<T>::row(lane, e)) * ld + wn0 + j * 16 + (lane & 15)];
-    }
+            for (int e = 0; e < 4; ++e)
+                acc[i][j][e] = (preload && live)
+                                   ? Ct[(size_t)(wm0 + i * 16 + Mfma<T>::row(lane, e)) * ldC + wn0 + j * 16 + (lane & 15)] : (T)0;
     T ra[EA], rb[EB];
-    load_stage<T, MK, HOST_TM, HOST_NT>(A0, ld, 0, ra, tid);
-    load_stage<T, MK, HOST_TN, HOST_NT>(B0, ld, 0, rb, tid);
+    load_stage<T, MK, HOST_TM, HOST_NT>(A0, ldA, 0, ra, tid);
+    load_stage<T, LB, HOST_TN, HOST_NT>(B0, ldB, 0, rb, tid);
     const int l15 = lane & 15;
     for (int s = 0; s < nst; ++s) {
         const int buf = s & 1;
         store_stage<T, MK, HOST_TM, HOST_NT>(As + buf * KT * LDA, ra, tid);
-        store_stage<T, MK, HOST_TN, HOST_NT>(Bs + buf * KT * LDB, rb, tid);
+        store_stage<T, LB, HOST_TN, HOST_NT>(Bs + buf * KT * LDB, rb, tid);
         __syncthreads();
         if (s + 1 < nst) {
-            load_stage<T, MK, HOST_TM, HOST_NT>(A0, ld, (s + 1) * KT, ra, tid);
-            load_stage<T, MK, HOST_TN, HOST_NT>(B0, ld, (s + 1) * KT, rb, tid);
+            load_stage<T, MK, HOST_TM, HOST_NT>(A0, ldA, (s + 1) * KT, ra, tid);
+            load_stage<T, LB, HOST_TN, HOST_NT>(B0, ldB, (s + 1) * KT, rb, tid);
         }
-        if (live) {
+        if (live && s >= dead) {
             const T* as = As + buf * KT * LDA;
             const T* bs = Bs + buf * KT * LDB;
 #pragma unroll
@@ -1649,7 +1637,10 @@ __device__ __forceinline__ void host_tile_body(const HostArgs& a, int b, unsigne
                 const int kr = kk * 4 + (lane >> 4);
                 T af[4], bf[4];
 #pragma unroll
-                for (int i = 0; i < 4; ++i) af[i] = -as[kr * LDA + wm0 + swz_col<T>(i * 16, l15, kk)];
+                for (int i = 0; i < 4; ++i) {
+                    const T v = as[kr * LDA + wm0 + swz_col<T>(i * 16, l15, kk)];
+                    af[i] = NEG ? -v : v;
+                }
 #pragma unroll
                 for (int j = 0; j < 4; ++j) bf[j] = bs[kr * LDB + wn0 + swz_col<T>(j * 16, l15, kk)];
 #pragma unroll
@@ -1666,8 +1657,43 @@ __device__ __forceinline__ void host_tile_body(const HostArgs& a, int b, unsigne
             for (int j = 0; j < 4; ++j)
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
-                    Ct[(size_t)(wm0 + i * 16 + Mfma<T>::row(lane, e)) * ld + wn0 + j * 16 + (lane & 15)] = (T)acc[i][j][e];
+                    Ct[(size_t)(wm0 + i * 16 + Mfma<T>::row(lane, e)) * ldC + wn0 + j * 16 + (lane & 15)] = (T)acc[i][j][e];
     }
+}
+
+template <typename T>
+__device__ __forceinline__ void host_tile_body(const HostArgs& a, int b, unsigned char* lds) {
+    int ji = 0;
+    while (ji + 1 < a.njobs && b >= a.job[ji].nblk) { b -= a.job[ji].nblk; ++ji; }
+    const HostJob jb = a.job[ji];
+    const int k = b % a.q;
+    int t = b / a.q;
+    const int ld = a.npad;
+    const int tid = body_tid(), lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm0 = (wave >> 1) * 64, wn0 = (wave & 1) * 64;
+    const int nst = (jb.k1 - jb.k0) * (TS / KT);
+    T* Mk = (T*)a.M + (size_t)k * a.mat;
+    if (jb.type == lcgp_fill::HJ_TRI_T) {
+        // V[R, ct] (+)= L[R, k0 .. k1) W[k0 .. k1, ct]: the chunk that starts on the strip's own block row (k0 = 2 ct) begins
+        // with the triangular diagonal block of W11 -- its first 64 rows are zero in the columns 64 .. 127
+        const int R = jb.cp0 + t;
+        const T* Wk = (const T*)a.W + (size_t)k * a.mat;
+        T* Vk = (T*)a.V + (size_t)k * a.mat;
+        const int dead = (jb.k0 == 2 * jb.ct) ? wn0 / KT : 0;
+        host_tile_core<T, KM, false>(Mk + (size_t)R * HOST_TM * ld + (size_t)jb.k0 * TS, ld,
+                                     Wk + (size_t)jb.k0 * TS * ld + (size_t)jb.ct * HOST_TN, ld,
+                                     Vk + (size_t)R * HOST_TM * ld + (size_t)jb.ct * HOST_TN, ld, nst, !jb.first, true, dead, wm0, wn0,
+                                     tid, lane, lds);
+        return;
+    }
+    int cp = jb.cp0;
+    while (t >= 2 * (jb.np - cp)) { t -= 2 * (jb.np - cp); ++cp; }
+    const int R = cp + (t >> 1), ct = 2 * cp + (t & 1);            // 256-row block, 128-column tile
+    // the second column tile of the panel's own row block: its rows 0 .. 127 lie above the diagonal (never read by anyone)
+    const bool live = !(R == cp && (t & 1) && wm0 < 128);
+    host_tile_core<T, MK, true>(Mk + (size_t)R * HOST_TM * ld + (size_t)jb.k0 * TS, ld,
+                                Mk + (size_t)ct * HOST_TN * ld + (size_t)jb.k0 * TS, ld,
+                                Mk + (size_t)R * HOST_TM * ld + (size_t)ct * HOST_TN, ld, nst, true, live, 0, wm0, wn0, tid, lane, lds);
 }
 
 // The diagonal block [J, pe) x [J, pe) of component k on ONE workgroup of 256 threads: L in place, its 64 x 64 diagonal-block
@@ -1750,13 +1776,13 @@ constexpr int host_lds_bytes() {
 template <typename T>
 __global__ __launch_bounds__(HOST_NT, 2) void host_kernel(HostArgs a) {
     __shared__ __align__(16) unsigned char lds[host_lds_bytes<T>()];
-    if ((int)blockIdx.x < a.q) {
+    if ((int)blockIdx.x < a.nchain) {
         // waves 4 .. 7 of a chain workgroup leave at once: a barrier only counts the waves that are still running
         if (threadIdx.x >= 256) return;
         chain_panel_body<T>(lds, blockIdx.x, a);
         return;
     }
-    host_tile_body<T>(a, blockIdx.x - a.q, lds);
+    host_tile_body<T>(a, blockIdx.x - a.nchain, lds);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -2379,7 +2405,7 @@ inline int check_sched(const lcgp_sched& s) {
     if (s.outer_blocks < 0 || s.outer_blocks > 64) return bad("sched.outer_blocks must be in [0, 64]");
     if (s.syrk_small_tiles < 0 || s.trtri_small_tiles < 0 || s.lauum_small_tiles < 0 || s.trtri_level_small < 0 ||
         s.fill_leaf < 0 || s.fill_step < 0 || s.leaf_in_wide < 0 || s.progressive_tiles < 0 || s.progressive_lauum < 0 ||
-        s.hosted < 0 || s.hosted > 1 || s.hosted_defer < 1 || s.hosted_defer > 16)
+        s.hosted < 0 || s.hosted > 2 || s.hosted_defer < 1 || s.hosted_defer > 16)
         return bad("sched fields must be >= 0");
     return 0;
 }
@@ -2444,6 +2470,8 @@ struct PlanHeader {
     int dtype, n, nb, q, with_inverse;
     int nlaunch, npanel;
     int host_from;             // first block column of the hosted panels (nb: none)
+    int tri_h;                 // > 0: the triangular inverse is part of the plan -- W11 = L11^-1 of the leading tri_h block columns
+                               // in front of the hosted panels, its top-level product T = L21 W11 as hosted tiles, the rest behind
     int inverse_done;          // what the plan leaves behind the factorisation: 0 = L, 1 = and L^-1, 2 = and A^-1
     int num_cu;
     lcgp_sched sched;
@@ -2468,11 +2496,20 @@ inline lcgp_fill::PlanParams plan_params(int dtype, int nb, int q, bool with_inv
     return pp;
 }
 
-// first block column of the hosted panels for this shape and schedule (nb: none)
-inline int hosted_from(int dtype, int nb, int q, bool with_inverse, const lcgp_sched& sc) {
-    (void)dtype; (void)q; (void)with_inverse;
+// first block column of the hosted panels for this shape and schedule (nb: none).  hosted = 1: every panel; hosted = 2: the
+// panels behind the largest power-of-two block count below nb -- the right half of the top level of the triangular inverse,
+// whose product T = L21 W11 then rides on them (only when the inverse follows the factorisation)
+inline int hosted_from(int dtype, int nb, int q, bool with_inverse, const lcgp_sched& sc, int* tri_h) {
+    (void)dtype; (void)q;
+    *tri_h = 0;
     if (!sc.hosted || !lcgp_fill::HostPlanner::applicable(nb)) return nb;
-    return 0;
+    if (sc.hosted == 1) return 0;
+    if (!with_inverse) return nb;
+    int top = 1;
+    while (2 * top < nb) top *= 2;
+    if (top < 8 || nb - top < 8) return nb;        // (at least two hosted panels)
+    *tri_h = top;
+    return top;
 }
 
 // builds the plan into `out` (NULL: only the size is computed) or into `vec` (resized); returns the bytes, 0 on failure
@@ -2481,15 +2518,23 @@ inline size_t make_plan(int dtype, int n, int q, bool with_inverse, const lcgp_s
     const int npad = round_up(n, 2 * TS), nb = npad / TS;
     int inverse_done = 0;
     lcgp_fill::PlanParams pp = plan_params(dtype, nb, q, with_inverse, sc, &inverse_done);
-    const int hf = hosted_from(dtype, nb, q, with_inverse, sc);
-    if (hf < nb) { pp.stop_block = hf; pp.progressive = false; inverse_done = 0; }
+    int tri_h = 0;
+    const int hf = hosted_from(dtype, nb, q, with_inverse, sc, &tri_h);
+    if (hf < nb) { pp.stop_block = hf; pp.progressive = false; inverse_done = tri_h > 0 ? 1 : 0; }
     lcgp_fill::Planner plan(pp);
     plan.run();
     if (plan.failed) { bad("internal: the filler queue did not drain"); return 0; }
+    int dev = 0, ncu = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
+        ncu < 1)
+        ncu = 256;
+    (void)hipGetLastError();
     lcgp_fill::HostPlanner hplan(nb, q, sc.hosted_defer, hf / 4);
     if (hf < nb) {
+        hplan.tri_h = tri_h;
+        hplan.slots = ncu > q ? ncu - q : 1;
         hplan.run();
-        if (hplan.failed) { bad("internal: the hosted plan left a column panel behind"); return 0; }
+        if (hplan.failed) { bad("internal: the hosted plan left work behind"); return 0; }
     }
     PlanHeader h;
     memset(&h, 0, sizeof(h));
@@ -2498,13 +2543,9 @@ inline size_t make_plan(int dtype, int n, int q, bool with_inverse, const lcgp_s
     h.nlaunch = (int)plan.launches.size();
     h.npanel = (int)hplan.panels.size();
     h.host_from = hf;
+    h.tri_h = tri_h;
     h.inverse_done = inverse_done;
     h.sched = sc;
-    int dev = 0, ncu = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
-        ncu < 1)
-        ncu = 256;
-    (void)hipGetLastError();
     h.num_cu = ncu;
     h.off_launch = (sizeof(PlanHeader) + 255) & ~size_t(255);
     h.off_panel = (h.off_launch + sizeof(lcgp_fill::Launch) * h.nlaunch + 255) & ~size_t(255);
@@ -2527,6 +2568,9 @@ inline int check_plan(const void* plan_host, int dtype, int n, int q, bool with_
     return 0;
 }
 
+template <typename T>
+int do_trtri_part(hipStream_t st, const Ws& w, const lcgp_sched& sc, int mb_lo, int mb_hi, int b_lo, int b_hi, int which);
+
 // Hosted panels (see host_kernel): per outer panel the launch that factors its diagonal block beside deferred trailing
 // updates, the panel solve of the rows below and the rank-256 update of the next panel's columns.
 template <typename T>
@@ -2539,12 +2583,15 @@ int do_potrf_hosted(hipStream_t st, const Ws& w, const HostPanel* panels, int np
         HostArgs a;
         a.M = M; a.W = W; a.V = V; a.mat = w.mat; a.npad = w.npad; a.nb = w.nb; a.q = w.q;
         a.J = p.J; a.pe = p.pe;
+        a.nchain = p.J >= 0 ? w.q : 0;
         a.logdet = (double*)(w.base + w.off_logdet); a.info = (int*)(w.base + w.off_info);
         a.njobs = p.njobs;
         memcpy(a.job, p.job, sizeof(a.job));
-        hipLaunchKernelGGL((host_kernel<T>), dim3((unsigned)(w.q + p.nhost)), dim3(HOST_NT), 0, st, a);
-        CHECK_LAUNCH("host_kernel");
-        if (p.ne == p.pe) break;
+        if (a.nchain + p.nhost > 0) {
+            hipLaunchKernelGGL((host_kernel<T>), dim3((unsigned)(a.nchain + p.nhost)), dim3(HOST_NT), 0, st, a);
+            CHECK_LAUNCH("host_kernel");
+        }
+        if (p.ne == p.pe) continue;        // the last panel, or a launch of hosted tiles only
         // the rows below: L[R, panel] = X[R, panel] W_PP^T
         GemmArgs g;
         g.sA = g.sB = g.sC = w.mat; g.ldA = g.ldB = g.ldC = w.npad;
@@ -2640,7 +2687,18 @@ int do_potrf(hipStream_t st, const Ws& w, const lcgp_sched& sc, bool stats_zeroe
         }
         if (rc) return rc;
     }
-    if (h->npanel > 0) return do_potrf_hosted<T>(st, w, (const HostPanel*)((const char*)plan_host + h->off_panel), h->npanel);
+    if (h->npanel > 0) {
+        int rc = 0;
+        // the inverse as part of the plan: W11 = L11^-1 (every level below the top one) in front of the hosted panels, which
+        // carry the top-level product T = L21 W11; behind them the levels of the trailing part (the chains have left the
+        // first two) and W21 = -W22 T
+        if (h->tri_h > 0 && (rc = do_trtri_part<T>(st, w, h->sched, 1, h->tri_h, 0, h->tri_h, 0))) return rc;
+        if ((rc = do_potrf_hosted<T>(st, w, (const HostPanel*)((const char*)plan_host + h->off_panel), h->npanel))) return rc;
+        if (h->tri_h > 0) {
+            if ((rc = do_trtri_part<T>(st, w, h->sched, 4, h->tri_h, h->tri_h, 0, 0))) return rc;
+            if ((rc = do_trtri_part<T>(st, w, h->sched, h->tri_h, 2 * h->tri_h, 0, 0, 2))) return rc;
+        }
+    }
     return 0;
 }
 
@@ -2652,37 +2710,55 @@ inline bool use_small_tiles(const Ws& w, int threshold) {
     return (long long)w.q * (nb2 * (nb2 + 1) / 2) < threshold;
 }
 
+// one level of the triangular inverse: pairs of blocks of mb tiles (TM units), the pairs [p_lo, p_hi) (p_hi < 0: all);
+// which: 0 = T = L21 W11 and W21 = -W22 T, 1 = T only, 2 = W21 only (T is in V already)
 template <typename T, int TM>
-int trtri_level(hipStream_t st, const Ws& w, int mb) {      // one level: pairs of blocks of mb tiles (TM units)
+int trtri_level(hipStream_t st, const Ws& w, int mb, int p_lo = 0, int p_hi = -1, int which = 0) {
     GemmArgs g;
-    g.sA = g.sB = g.sC = w.mat; g.ldA = g.ldB = g.ldC = w.npad; g.p2 = g.p3 = 0;
+    g.sA = g.sB = g.sC = w.mat; g.ldA = g.ldB = g.ldC = w.npad; g.p3 = 0;
     const int nbt = w.npad / TM;
     g.nb = nbt;
-    const int pairs = (nbt + 2 * mb - 1) / (2 * mb);
-    g.p0 = mb; g.p1 = pairs;
-    g.A = (T*)(w.base + w.off_M); g.B = (T*)(w.base + w.off_W); g.C = (T*)(w.base + w.off_V);
-    int rc = launch_gemm<T, OP_TRTRI_T, TM>(st, g, pairs * mb * mb, w.q);
-    if (rc) return rc;
-    g.A = (T*)(w.base + w.off_W); g.B = (T*)(w.base + w.off_V); g.C = (T*)(w.base + w.off_W);
-    return launch_gemm<T, OP_TRTRI_W, TM>(st, g, pairs * mb * mb, w.q);
+    const int all = (nbt + 2 * mb - 1) / (2 * mb);
+    if (p_hi < 0 || p_hi > all) p_hi = all;
+    const int pairs = p_hi - p_lo;
+    if (pairs <= 0) return 0;
+    g.p0 = mb; g.p1 = pairs; g.p2 = p_lo;
+    int rc = 0;
+    if (which != 2) {
+        g.A = (T*)(w.base + w.off_M); g.B = (T*)(w.base + w.off_W); g.C = (T*)(w.base + w.off_V);
+        rc = launch_gemm<T, OP_TRTRI_T, TM>(st, g, pairs * mb * mb, w.q);
+        if (rc) return rc;
+    }
+    if (which != 1) {
+        g.A = (T*)(w.base + w.off_W); g.B = (T*)(w.base + w.off_V); g.C = (T*)(w.base + w.off_W);
+        rc = launch_gemm<T, OP_TRTRI_W, TM>(st, g, pairs * mb * mb, w.q);
+    }
+    return rc;
 }
 
+// The levels mb64 = mb_lo, 2 mb_lo, .. < mb_hi of W = L^-1 (64-block units: mb64 = 1 joins pairs of 64-blocks) for the pairs
+// that lie in the block range [b_lo, b_hi) (b_hi <= 0: to the end); mb64 = 1 always on 64x64 tiles, a further level on
+// 128x128 tiles unless the whole inverse or the whole level is too small to fill the chip with them.
 template <typename T>
-int do_trtri(hipStream_t st, const Ws& w, const lcgp_sched& sc) {
+int do_trtri_part(hipStream_t st, const Ws& w, const lcgp_sched& sc, int mb_lo, int mb_hi, int b_lo, int b_hi, int which) {
     const bool all_small = use_small_tiles(w, sc.trtri_small_tiles);
-    // levels in 64-block units: mb64 = 1 joins pairs of 64-blocks (always 64x64 tiles); a further level works on 128x128
-    // tiles unless the whole inverse or this level is too small to fill the chip with them
-    for (int mb64 = 1; mb64 < w.nb; mb64 *= 2) {
+    for (int mb64 = mb_lo; mb64 < mb_hi && mb64 < w.nb; mb64 *= 2) {
         bool small = all_small || mb64 == 1;
         if (!small) {
             const int mb = mb64 / 2, nbt = w.npad / 128;
             const long long tiles = (long long)((nbt + 2 * mb - 1) / (2 * mb)) * mb * mb * w.q;
             small = tiles < sc.trtri_level_small;
         }
-        const int rc = small ? trtri_level<T, 64>(st, w, mb64) : trtri_level<T, 128>(st, w, mb64 / 2);
+        const int p_lo = b_lo / (2 * mb64), p_hi = b_hi > 0 ? b_hi / (2 * mb64) : -1;
+        const int rc = small ? trtri_level<T, 64>(st, w, mb64, p_lo, p_hi, which) : trtri_level<T, 128>(st, w, mb64 / 2, p_lo, p_hi, which);
         if (rc) return rc;
     }
     return 0;
+}
+
+template <typename T>
+int do_trtri(hipStream_t st, const Ws& w, const lcgp_sched& sc) {
+    return do_trtri_part<T>(st, w, sc, 1, w.nb, 0, 0, 0);
 }
 
 template <typename T>
