@@ -82,11 +82,6 @@ typedef struct lcgp_sched {
     int progressive_lauum;  /* with the progressive inverse: A^-1 = W^T W is accumulated behind the chain as well when the matrix
                                has at most this many 64-blocks per side (48); beyond, only L^-1 is, and A^-1 takes the one
                                launch of lcgp_lauum after the factorisation (0 = always that) */
-    int hosted;             /* 1 = hosted panels: ONE launch per outer panel of 256 columns in which one workgroup per component
-                               factors and inverts the panel's whole diagonal block while all other workgroups run deferred
-                               trailing updates (256x128 tiles, long K), followed by the panel solve of the rows below and the
-                               rank-256 update of the next panel's columns (n padded must be a multiple of 256, at least 512) */
-    int hosted_defer;       /* hosted panels: a column panel receives the finished panels in groups of this many (2) */
 } lcgp_sched;
 int lcgp_sched_default(lcgp_sched* sched /*host out*/);
 
@@ -155,12 +150,12 @@ int lcgp_nll_grad(void* stream, int dtype, int n, int d, int p, int q_local,
  * owned by the caller, passed to lcgp_nll_grad / lcgp_potrf_logdet, whose `sched` argument is then ignored (the plan
  * carries the schedule it was built for).  plan = NULL: the plan is computed per call.  The library still keeps no
  * state.  Replaces nothing in the reference: it is the cost of ~120 kernel launches the reference never had.
- * lcgp_plan_info: launches of the launch-by-launch part, hosted panels behind it, and what the plan leaves behind the
- * factorisation (0 = L, 1 = and L^-1, 2 = and A^-1). */
+ * lcgp_plan_info: number of launches, and what the plan leaves behind the factorisation (0 = L, 1 = and L^-1,
+ * 2 = and A^-1). */
 int lcgp_plan_bytes(int dtype, int n, int q_local, int with_inverse, const lcgp_sched* sched, size_t* bytes /*host out*/);
 int lcgp_plan_build(int dtype, int n, int q_local, int with_inverse, const lcgp_sched* sched,
                     void* plan /*host out*/, size_t bytes);
-int lcgp_plan_info(const void* plan /*host*/, int* nlaunch, int* npanel, int* inverse_done);
+int lcgp_plan_info(const void* plan /*host*/, int* nlaunch, int* inverse_done);
 
 /* Assembles this rank's share of the vector the ranks all-reduce (in the reference the sum over
  * k of lcgp.py:650-661 and the gradient tape's accumulation), on the device, in a fixed summation order:

@@ -24,8 +24,7 @@ class Sched(C.Structure):
     """lcgp_sched of include/lcgp_hip.h: launch shapes of the factorisation / inverse, passed per call."""
     _fields_ = [("outer_blocks", C.c_int), ("syrk_small_tiles", C.c_int), ("trtri_small_tiles", C.c_int),
                 ("lauum_small_tiles", C.c_int), ("trtri_level_small", C.c_int), ("fill_leaf", C.c_int),
-                ("fill_step", C.c_int), ("leaf_in_wide", C.c_int), ("progressive_tiles", C.c_int), ("progressive_far", C.c_int), ("progressive_lauum", C.c_int),
-                ("hosted", C.c_int), ("hosted_defer", C.c_int)]
+                ("fill_step", C.c_int), ("leaf_in_wide", C.c_int), ("progressive_tiles", C.c_int), ("progressive_far", C.c_int), ("progressive_lauum", C.c_int)]
 
 
 # every symbol include/lcgp_hip.h declares: name -> (restype, argtypes)
@@ -52,7 +51,7 @@ SIGNATURES = {
     "lcgp_nll_grad": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _sp, _vp]),
     "lcgp_plan_bytes": (_i, [_i, _i, _i, _i, _sp, C.POINTER(C.c_size_t)]),
     "lcgp_plan_build": (_i, [_i, _i, _i, _i, _sp, _vp, C.c_size_t]),
-    "lcgp_plan_info": (_i, [_vp, C.POINTER(_i), C.POINTER(_i), C.POINTER(_i)]),
+    "lcgp_plan_info": (_i, [_vp, C.POINTER(_i), C.POINTER(_i)]),
     "lcgp_pack_partial": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "lcgp_predict": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp, _i, _vp, _vp, _vp, _i]),
 }

@@ -275,8 +275,6 @@ struct PlanParams {
     bool far_rides;          // the far columns of a trailing update ride on the next panel's chain (else: one wide launch)
     bool with_dupd = true;   // progressive: A^-1 = W^T W is accumulated behind the chain too (else only L^-1 is; the caller
                              // then forms A^-1 in one launch after the factorisation)
-    int stop_block = -1;     // >= 0: only the panels in front of this block column are planned (0: none), the last of them with
-                             // its WHOLE trailing update as one wide launch (hosted panels follow: lcgp_hip.hip, HostPlanner)
 };
 
 enum LaunchKind {
@@ -309,7 +307,6 @@ class Planner {
         const int nb = pp.nb, ob = pp.ob, q = pp.q;
         const bool t128 = (ob & 1) == 0;
         inverse_planned = pp.progressive;
-        if (pp.stop_block == 0) return;
         bool leaf_done = false;
         // filler capacity of a panel's chain launches, with and without a diagonal-block launch of its own
         const int cap_with_leaf = pp.fill_leaf + (ob - 1) * pp.fill_step;
@@ -338,9 +335,7 @@ class Planner {
             // carries filler of its own and the 8-wave tile kernel is the faster one.
             int cf = nb;                                       // first filler column
             bool next_leaf = false;
-            const bool last_planned = pp.stop_block > 0 && pe >= pp.stop_block;      // hosted panels follow: no filler, no
-                                                                                      // diagonal block in the update launch
-            if (pe < nb && !last_planned) {
+            if (pe < nb) {
                 cf = first_filler_column(pp.far_rides ? cap_with_leaf : 0);
                 if (pp.leaf_in_wide && !wide128(cf)) {
                     const int cf3 = first_filler_column(pp.far_rides ? cap_no_leaf : 0);
@@ -363,7 +358,6 @@ class Planner {
             }
             leaf_done = next_leaf && pe < cf;
             queue_far_update(J, pe, cf);
-            if (last_planned) break;
         }
         // the tail of the progressive inverse: what the chain launches did not carry, in as few dependent launches as
         // the job dependencies allow; the remaining A^-1 updates merged into K bands
@@ -506,171 +500,6 @@ class Planner {
         }
         fq.syrk_job = -1;
     }
-};
-
-// ---------------------------------------------------------------------------------------------------
-// Hosted panels (lcgp_hip.hip: host_kernel).  Per outer panel P of `ob` = 4 block columns three launches:
-//   A(P)  q chain workgroups factor the panel's whole diagonal block (and invert it), all other workgroups run DEFERRED
-//         trailing updates: jobs (column panels, K range) -- 256 x 128 tiles of  M[R, c] -= sum_{k0 <= k < k1} L[R, k] L[c, k]^T;
-//   B(P)  the panel solve of the rows below,  L[R, P] = X[R, P] W_PP^T  (X = the updated panel: in the scratch matrix V, where
-//         C(P-1) left it; panel 0 is solved in place, one launch per block column from the right);
-//   C(P)  the rank-(64 ob) update of the NEXT panel's columns only (its diagonal block back into M, the rows below into V).
-// Left-looking at the outer level: column panel c receives the finished panels in groups of `defer` (one visit with
-// K = 64 ob defer instead of `defer` read-modify-write passes), staggered so that every launch carries about the same
-// share: column c is visited by A(P) when (c - 1 - P) is a multiple of `defer` -- which makes the visit of A(c - 1), the
-// last chance before the column's own chain, a regular one.  tests/test_fill_sched.py replays the plan on numpy matrices.
-// ---------------------------------------------------------------------------------------------------
-constexpr int HOST_NJ = 24;
-
-enum HostJobType { HJ_UPDATE = 0, HJ_TRI_T = 1 };
-
-struct HostJob {
-    int type;
-    // HJ_UPDATE: deferred trailing update of the column panels cp0 .. cp0 + ncp - 1 (256 columns = two 128-column tiles each;
-    // column panel c has the 256-row blocks c .. np - 1):  M[R, c] -= sum_{k0 <= k < k1} L[R, k] L[c, k]^T
-    // HJ_TRI_T:  one K chunk of the top-level product of the triangular inverse, T = L21 W11 (into V), for the 128-column tile
-    // `ct` and the 256-row blocks cp0 .. cp0 + ncp - 1:  V[R, ct] (+)= sum_{k0 <= k < k1} L[R, k] W[k, ct]   (`first`: written)
-    int cp0, ncp;
-    int k0, k1;          // K range in 64-blocks
-    int np;              // panels per side
-    int ct, first;
-    int nblk;            // blocks = tiles x components (component = fastest index); HJ_UPDATE: column panel by column panel,
-                         // row block by row block, the two column tiles of a row block adjacent; HJ_TRI_T: row block by row block
-};
-
-inline long host_job_tiles(int cp0, int ncp, int np) {
-    long n = 0;
-    for (int c = cp0; c < cp0 + ncp; ++c) n += 2L * (np - c);
-    return n;
-}
-
-struct HostPanel {
-    HostPanel() { memset((void*)this, 0, sizeof(*this)); }
-    int J, pe, ne;       // the panel's block columns [J, pe), the next panel's [pe, ne)  (ne = pe: the last panel);
-                         // J < 0: no panel at all -- a launch of hosted tiles only (what the panels could not carry)
-    int njobs;
-    int nhost;           // blocks of all jobs
-    HostJob job[HOST_NJ];
-};
-
-class HostPlanner {
- public:
-    // nb: 64-blocks per side (a multiple of ob = 4), q components, defer >= 1, first hosted panel p0 (the panels in front of
-    // it have been factored AND applied to everything behind them: right-looking up to there)
-    HostPlanner(int nb_, int q_, int defer_, int p0_ = 0) : nb(nb_), q(q_), defer(defer_ < 1 ? 1 : defer_), p0(p0_) {}
-    std::vector<HostPanel> panels;
-    bool failed = false;
-    static bool applicable(int nb) { return nb >= 8 && nb % 4 == 0; }
-
-    // The top-level product of the triangular inverse rides on the hosted panels: T = L[tri_h.., 0..tri_h) W[0..tri_h, 0..tri_h)
-    // (tri_h = 4 p0 block columns: everything it reads is final when the first hosted panel starts -- the caller has formed
-    // W11 = L11^-1 in front of it).  Column strips of 128 x K chunks of at most `chunk` 64-blocks, walked from the last block row
-    // of W11 upwards; a launch takes chunks while its workgroups besides the chain are estimated to finish with the chain.
-    int tri_h = 0;
-    int slots = 248;             // compute units besides the chain workgroups
-    double chain_us = 165.0;     // the chain workgroup of a panel (measured: 157 alone, 165-177 beside a full chip)
-    double unit_us = 36.0;       // a 256 x 128 tile per 128 of K (measured: 34 alone, 37 beside a full chip)
-    double tile_us = 8.0;        // ... plus its two ends
-    int chunk = 8;
-
-    void run() {
-        const int ob = 4, np = nb / ob;
-        std::vector<int> applied(np, p0);         // panels [0, applied[c]) have been applied to column panel c
-        // K chunks of the strips of T, in the order they may run: chunk index first (a strip's chunks must follow each other
-        // in DIFFERENT launches), strips left to right (longest K first)
-        struct Chunk { int ct, k0, k1, idx; };
-        std::vector<Chunk> chunks;
-        if (tri_h > 0) {
-            const int nst = tri_h / 2;
-            for (int idx = 0;; ++idx) {
-                bool any = false;
-                for (int ct = 0; ct < nst; ++ct) {
-                    const int len = tri_h - 2 * ct;                       // the strip's K range [2 ct, tri_h) in 64-blocks
-                    const int nch = (len + chunk - 1) / chunk;
-                    if (idx >= nch) continue;
-                    // even split in multiples of two blocks, the longer chunks first (from the bottom of W11 upwards)
-                    const int pairs = len / 2, base = pairs / nch, extra = pairs % nch;
-                    int hi = tri_h;
-                    for (int i = 0; i < idx; ++i) hi -= 2 * (base + (i < extra ? 1 : 0));
-                    const int lo = hi - 2 * (base + (idx < extra ? 1 : 0));
-                    chunks.push_back({ct, lo, hi, idx});
-                    any = true;
-                }
-                if (!any) break;
-            }
-        }
-        size_t next_chunk = 0;
-        auto tile_cost = [&](int kblocks) { return tile_us + unit_us * kblocks / 2.0; };
-        auto take_chunks = [&](HostPanel& hp, double budget) {
-            // (CU-microseconds left beside the panel's own jobs)
-            std::vector<int> strips;
-            const int nr = np - p0;
-            while (next_chunk < chunks.size() && hp.njobs < HOST_NJ) {
-                const Chunk& c = chunks[next_chunk];
-                bool clash = false;
-                for (int s : strips) clash = clash || s == c.ct;
-                const double cost = (double)nr * q * tile_cost(c.k1 - c.k0);
-                if (clash || cost > budget) break;
-                HostJob& j = hp.job[hp.njobs++];
-                j.type = HJ_TRI_T; j.cp0 = p0; j.ncp = nr; j.k0 = c.k0; j.k1 = c.k1; j.np = np; j.ct = c.ct; j.first = c.idx == 0 ? 1 : 0;
-                budget -= cost;
-                strips.push_back(c.ct);
-                ++next_chunk;
-            }
-        };
-        auto finish = [&](HostPanel& hp) {
-            // longest K first
-            for (int i = 1; i < hp.njobs; ++i)
-                for (int j = i; j > 0 && hp.job[j].k1 - hp.job[j].k0 > hp.job[j - 1].k1 - hp.job[j - 1].k0; --j)
-                    std::swap(hp.job[j], hp.job[j - 1]);
-            for (int i = 0; i < hp.njobs; ++i) {
-                HostJob& j = hp.job[i];
-                j.nblk = (int)((j.type == HJ_TRI_T ? (long)j.ncp : host_job_tiles(j.cp0, j.ncp, np)) * q);
-                hp.nhost += j.nblk;
-            }
-            panels.push_back(hp);
-        };
-        for (int P = p0; P < np; ++P) {
-            HostPanel hp;
-            hp.J = P * ob; hp.pe = hp.J + ob; hp.ne = P + 1 < np ? hp.pe + ob : hp.pe;
-            double own = 0.0;
-            for (int c = P + 1; c < np; ++c) {
-                if (applied[c] >= P) continue;
-                if (c != P + 1 && (c - 1 - P) % defer != 0) continue;
-                own += 2.0 * (np - c) * q * tile_cost((P - applied[c]) * ob);
-                // merge with the previous job when it is the column panel next to it with the same K range
-                if (hp.njobs > 0) {
-                    HostJob& pj = hp.job[hp.njobs - 1];
-                    if (pj.cp0 + pj.ncp == c && pj.k0 == applied[c] * ob) {
-                        ++pj.ncp;
-                        applied[c] = P;
-                        continue;
-                    }
-                }
-                if (hp.njobs >= HOST_NJ) { own -= 2.0 * (np - c) * q * tile_cost((P - applied[c]) * ob); continue; }
-                                                                   // (stays pending: a later launch takes it with a longer K)
-                HostJob& j = hp.job[hp.njobs++];
-                j.type = HJ_UPDATE; j.cp0 = c; j.ncp = 1; j.k0 = applied[c] * ob; j.k1 = P * ob; j.np = np;
-                applied[c] = P;
-            }
-            if (P + 1 < np && applied[P + 1] != P) { failed = true; return; }
-            take_chunks(hp, (double)slots * chain_us - own);
-            finish(hp);
-            if (P + 1 < np) applied[P + 1] = P + 1;      // C(P)
-        }
-        // what the panels could not carry: launches of tiles only, a strip's chunks still one launch apart
-        int guard = 0;
-        while (next_chunk < chunks.size()) {
-            HostPanel hp;
-            hp.J = hp.pe = hp.ne = -1;
-            take_chunks(hp, 1e30);
-            if (hp.njobs == 0 || ++guard > 4 * nb) { failed = true; return; }
-            finish(hp);
-        }
-    }
-
- private:
-    int nb, q, defer, p0;
 };
 
 }  // namespace lcgp_fill

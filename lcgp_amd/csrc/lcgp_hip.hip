@@ -654,7 +654,7 @@ __global__ __launch_bounds__(256, 2) void leaf_kernel(T* __restrict__ M, T* __re
 //   MK : element (m, k) at P[m * ld + k]      KM : element (m, k) at P[k * ld + m]
 // and staged in LDS as [k][m] (KT = 16 k rows per stage, double buffered through registers).
 // ---------------------------------------------------------------------------------------------------
-enum GemmOp { OP_SYRK = 1, OP_TRTRI_T = 2, OP_TRTRI_W = 3, OP_LAUUM = 4, OP_PRED_U = 5, OP_PSOLVE = 6 };
+enum GemmOp { OP_SYRK = 1, OP_TRTRI_T = 2, OP_TRTRI_W = 3, OP_LAUUM = 4, OP_PRED_U = 5 };
 enum Lay { MK = 0, KM = 1 };
 
 struct GemmArgs {
@@ -669,9 +669,6 @@ struct GemmArgs {
                                                 // (the diagonal block there is factored by the same launch, wide_leaf_kernel)
     const void* bvec = nullptr;                 // OP_LAUUM on 128-tiles: b (npad per component) and the partial buffer of
     double* part = nullptr;                     // z = A^-1 b, [component][tile][2][128]; null = no fused product
-    void* C2 = nullptr; int r_c2 = 0;           // OP_SYRK: tiles of the rows >= r_c2 are STORED into this matrix instead of C
-                                                // (hosted panels: the rows below the next diagonal block go to the scratch
-                                                // matrix, from where the out-of-place panel solve reads them)
 };
 
 // one K-stage (KT = 16 k values) of a TM-row operand tile: global -> registers -> LDS [k][m], ld = TM + 16;
@@ -793,7 +790,6 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, const int lin /*blo
 
     // ---- per-op tile decode: A0/B0 = first operand tiles, dA/dB = pointer step per kt, nkt, C tile ----
     const T* A0; const T* B0; T* Ct;
-    T* Cs = nullptr;            // OP_SYRK: where the tile is stored when not in place (GemmArgs::C2)
     ptrdiff_t dA, dB;           // signed: some ops walk their k tiles downwards (see below)
     int nkt;
     double alpha = 1.0;
@@ -809,7 +805,6 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, const int lin /*blo
         B0 = Bb + (size_t)c * TM * g.ldB + (size_t)g.p0 * TM; dB = TM;
         nkt = g.p1 - g.p0;
         Ct = Cb + (size_t)r * TM * g.ldC + (size_t)c * TM;
-        Cs = (g.C2 && r >= g.r_c2) ? (T*)g.C2 + (size_t)k * g.sC + (size_t)r * TM * g.ldC + (size_t)c * TM : Ct;
         alpha = -1.0; accumulate = true;
     } else if constexpr (OP == OP_TRTRI_T || OP == OP_TRTRI_W) {
         // level with block size mb = p0: pair pr covers block rows [2 pr mb, 2 pr mb + 2 mb).
@@ -848,20 +843,6 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, const int lin /*blo
         nkt = g.nb - r;
         tri_b = r == c;
         Ct = Cb + (size_t)r * TM * g.ldC + (size_t)c * TM;
-    } else if constexpr (OP == OP_PSOLVE) {
-        // Panel solve of the rows below the chain rows (fill_sched.h: L_PSOLVE), in place in M:
-        //   L[R, c0 + jt] = sum_{kt = 0}^{jt} A[R, c0 + kt] W[c0 + jt, c0 + kt]^T      c0 = p0: first tile column of the panel,
-        // jt = p1, R = p2 + bid; W_PP = the panel's block of L^-1 (lower triangular: the last k tile is its diagonal tile).
-        // The tile it overwrites is its own last A operand: every global read of the k loop has been consumed through LDS
-        // before the loop's last barrier, the stores come after it.
-        // p3 > 0: OUT of place (A in another matrix than C) and all p3 column tiles of the panel in ONE launch, the longest
-        // K loops first: tile bid = (p3 - 1 - jt) * rows + (R - p2), rows = nb - p2.
-        const int rows = g.nb - g.p2;
-        const int R = g.p2 + (g.p3 > 0 ? bid % rows : bid), jt = g.p3 > 0 ? g.p3 - 1 - bid / rows : g.p1, c0 = g.p0;
-        A0 = Ab + (size_t)R * TM * g.ldA + (size_t)c0 * TM; dA = TM;
-        B0 = Bb + (size_t)(c0 + jt) * TM * g.ldB + (size_t)c0 * TM; dB = TM;
-        nkt = jt + 1;
-        Ct = Cb + (size_t)R * TM * g.ldC + (size_t)(c0 + jt) * TM;
     } else {
         // OP_PRED_U: U[m, r] = sum_{kt = 0}^{r} X[m, kt] W[r, kt]^T    (X = scaled cross covariance, n0pad x npad)
         const int r = g.nb - 1 - bid / g.p0, m = bid % g.p0;       // p0 = row tiles of X; longest k loops (large r) first
@@ -910,7 +891,7 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, const int lin /*blo
     if constexpr (OP == OP_LAUUM) { dead_lo = tri_first; dead_hi = tri_first + (tri_b && wn0 > wm0 ? wn0 : wm0) / KT; }
     else if constexpr (OP == OP_TRTRI_T) { dead_lo = tri_first; dead_hi = tri_first + wn0 / KT; }
     else if constexpr (OP == OP_TRTRI_W) dead_lo = tri_first + (wm0 + WTM) / KT;
-    else if constexpr (OP == OP_PRED_U || OP == OP_PSOLVE) dead_lo = tri_first + (wn0 + WTN) / KT;
+    else if constexpr (OP == OP_PRED_U) dead_lo = tri_first + (wn0 + WTN) / KT;
     auto wave_live = [&](int sg) { return !HAS_TRI || sg < dead_lo || sg >= dead_hi; };
     auto compute_stage = [&](int buf) {
         const T* as = As + buf * KT * LD;
@@ -998,7 +979,7 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, const int lin /*blo
             for (int e = 0; e < 4; ++e) {
                 const int row = wm0 + mi * 16 + Mfma<T>::row(lane, e);
                 const int col = wn0 + ni * 16 + (lane & 15);
-                T* dst = (OP == OP_SYRK ? Cs : Ct) + (size_t)row * g.ldC + col;
+                T* dst = Ct + (size_t)row * g.ldC + col;
                 if constexpr (OP == OP_SYRK && TM == 128) {
                     if (g.skipq && bid + g.t0 == 0 && row < TS && col < TS) continue;
                 }
@@ -1560,229 +1541,6 @@ __global__ __launch_bounds__(256, 2) void wide_leaf_kernel(GemmArgs g, T* __rest
         return;
     }
     gemm_body<T, OP_SYRK, TM, 4>(g, blockIdx.x - q, lds);
-}
-
-// ---------------------------------------------------------------------------------------------------
-// Hosted panels (lcgp_sched.hosted; fill_sched.h: HostPlanner).  ONE launch per outer panel of four block columns:
-//   * the first q workgroups (one per component, four of their eight waves) factor the panel's WHOLE 256 x 256 diagonal block
-//     -- the four 64 x 64 diagonal blocks (leaf_body), the six solve tiles between them with their left-looking updates,
-//     and the block's complete inverse W_PP (the first two levels of the triangular inverse) -- with no other workgroup
-//     involved: the latency chain of a panel is one workgroup's program instead of five dependent launches;
-//   * every other workgroup runs DEFERRED trailing updates, 256 x 128 tiles on eight waves with a long K loop:
-//     M[R, c] -= sum_{k in [k0, k1)} L[R, k] L[c, k]^T for column panels c to the right of the current one and the finished
-//     panels k the column has not received yet (left-looking at the outer level: a column is visited once per two or more
-//     panels instead of once per panel).  Nothing here touches what the chain workgroups read or write.
-// No workgroup of the launch depends on another one; stream order between launches is the only ordering.  The kernel is
-// compiled for ONE workgroup of 512 threads per CU (256 registers per lane: what the diagonal-block code needs; the
-// 256 x 128 tile holds 97 % of the two-workgroup rate of the 128 x 128 kernel that way, tools/tile_shape_bench.hip).
-// Behind it per panel: the panel solve of the rows below (OP_PSOLVE with W_PP) and the rank-256 update of the NEXT panel's
-// columns only (OP_SYRK), both short wide launches.
-// ---------------------------------------------------------------------------------------------------
-using lcgp_fill::HostJob;
-using lcgp_fill::HostPanel;
-using lcgp_fill::HOST_NJ;
-
-struct HostArgs {
-    void* M; void* W; void* V; size_t mat; int npad, nb, q;
-    int J, pe;                      // the panel's block columns [J, pe)
-    int nchain;                     // chain workgroups in front of the tiles: q, or 0 for a launch of hosted tiles only
-    double* logdet; int* info;
-    int njobs;
-    HostJob job[HOST_NJ];
-};
-
-constexpr int HOST_TM = 256, HOST_TN = 128, HOST_NT = 512;
-template <typename T>
-constexpr int host_tile_lds() { return 2 * KT * (HOST_TM + 16 + HOST_TN + 16) * (int)sizeof(T); }
-
-// One 256 x 128 tile on eight waves (64 x 64 per wave):  C (-)= sum over nst stages of 16 k  A(256 x k) B(128 x k)^T-like,
-// A with k contiguous (MK), B in either layout; `preload`: the accumulators start from the C tile (else from zero);
-// a wave that is not `live` only helps staging; stages [0, dead) of a live wave add exact zeros (a triangular B) and are skipped.
-template <typename T, int LB, bool NEG>
-__device__ __forceinline__ void host_tile_core(const T* __restrict__ A0, int ldA, const T* __restrict__ B0, int ldB,
-                                               T* __restrict__ Ct, int ldC, int nst, bool preload, bool live, int dead,
-                                               int wm0, int wn0, int tid, int lane, unsigned char* lds) {
-    constexpr int LDA = HOST_TM + 16, LDB = HOST_TN + 16;
-    constexpr int EA = HOST_TM * KT / HOST_NT, EB = HOST_TN * KT / HOST_NT;
-    T* As = (T*)lds;                    // [2][KT * LDA]
-    T* Bs = As + 2 * KT * LDA;          // [2][KT * LDB]
-    typedef typename Mfma<T>::acc_t acc_t;
-    acc_t acc[4][4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-                acc[i][j][e] = (preload && live)
-                                   ? Ct[(size_t)(wm0 + i * 16 + Mfma<T>::row(lane, e)) * ldC + wn0 + j * 16 + (lane & 15)] : (T)0;
-    T ra[EA], rb[EB];
-    load_stage<T, MK, HOST_TM, HOST_NT>(A0, ldA, 0, ra, tid);
-    load_stage<T, LB, HOST_TN, HOST_NT>(B0, ldB, 0, rb, tid);
-    const int l15 = lane & 15;
-    for (int s = 0; s < nst; ++s) {
-        const int buf = s & 1;
-        store_stage<T, MK, HOST_TM, HOST_NT>(As + buf * KT * LDA, ra, tid);
-        store_stage<T, LB, HOST_TN, HOST_NT>(Bs + buf * KT * LDB, rb, tid);
-        __syncthreads();
-        if (s + 1 < nst) {
-            load_stage<T, MK, HOST_TM, HOST_NT>(A0, ldA, (s + 1) * KT, ra, tid);
-            load_stage<T, LB, HOST_TN, HOST_NT>(B0, ldB, (s + 1) * KT, rb, tid);
-        }
-        if (live && s >= dead) {
-            const T* as = As + buf * KT * LDA;
-            const T* bs = Bs + buf * KT * LDB;
-#pragma unroll
-            for (int kk = 0; kk < KT / 4; ++kk) {
-                const int kr = kk * 4 + (lane >> 4);
-                T af[4], bf[4];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const T v = as[kr * LDA + wm0 + swz_col<T>(i * 16, l15, kk)];
-                    af[i] = NEG ? -v : v;
-                }
-#pragma unroll
-                for (int j = 0; j < 4; ++j) bf[j] = bs[kr * LDB + wn0 + swz_col<T>(j * 16, l15, kk)];
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) acc[i][j] = Mfma<T>::run(af[i], bf[j], acc[i][j]);
-            }
-        }
-    }
-    if (live) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-#pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    Ct[(size_t)(wm0 + i * 16 + Mfma<T>::row(lane, e)) * ldC + wn0 + j * 16 + (lane & 15)] = (T)acc[i][j][e];
-    }
-}
-
-template <typename T>
-__device__ __forceinline__ void host_tile_body(const HostArgs& a, int b, unsigned char* lds) {
-    int ji = 0;
-    while (ji + 1 < a.njobs && b >= a.job[ji].nblk) { b -= a.job[ji].nblk; ++ji; }
-    const HostJob jb = a.job[ji];
-    const int k = b % a.q;
-    int t = b / a.q;
-    const int ld = a.npad;
-    const int tid = body_tid(), lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm0 = (wave >> 1) * 64, wn0 = (wave & 1) * 64;
-    const int nst = (jb.k1 - jb.k0) * (TS / KT);
-    T* Mk = (T*)a.M + (size_t)k * a.mat;
-    if (jb.type == lcgp_fill::HJ_TRI_T) {
-        // V[R, ct] (+)= L[R, k0 .. k1) W[k0 .. k1, ct]: the chunk that starts on the strip's own block row (k0 = 2 ct) begins
-        // with the triangular diagonal block of W11 -- its first 64 rows are zero in the columns 64 .. 127
-        const int R = jb.cp0 + t;
-        const T* Wk = (const T*)a.W + (size_t)k * a.mat;
-        T* Vk = (T*)a.V + (size_t)k * a.mat;
-        const int dead = (jb.k0 == 2 * jb.ct) ? wn0 / KT : 0;
-        host_tile_core<T, KM, false>(Mk + (size_t)R * HOST_TM * ld + (size_t)jb.k0 * TS, ld,
-                                     Wk + (size_t)jb.k0 * TS * ld + (size_t)jb.ct * HOST_TN, ld,
-                                     Vk + (size_t)R * HOST_TM * ld + (size_t)jb.ct * HOST_TN, ld, nst, !jb.first, true, dead, wm0, wn0,
-                                     tid, lane, lds);
-        return;
-    }
-    int cp = jb.cp0;
-    while (t >= 2 * (jb.np - cp)) { t -= 2 * (jb.np - cp); ++cp; }
-    const int R = cp + (t >> 1), ct = 2 * cp + (t & 1);            // 256-row block, 128-column tile
-    // the second column tile of the panel's own row block: its rows 0 .. 127 lie above the diagonal (never read by anyone)
-    const bool live = !(R == cp && (t & 1) && wm0 < 128);
-    host_tile_core<T, MK, true>(Mk + (size_t)R * HOST_TM * ld + (size_t)jb.k0 * TS, ld,
-                                Mk + (size_t)ct * HOST_TN * ld + (size_t)jb.k0 * TS, ld,
-                                Mk + (size_t)R * HOST_TM * ld + (size_t)ct * HOST_TN, ld, nst, true, live, 0, wm0, wn0, tid, lane, lds);
-}
-
-// The diagonal block [J, pe) x [J, pe) of component k on ONE workgroup of 256 threads: L in place, its 64 x 64 diagonal-block
-// inverses and then the whole block inverse W_PP in W (scratch: the same block of V).  Left-looking inside the block: the tile
-// (r, c) receives the columns J .. c-1 when its own column is factored; the diagonal tiles are updated as soon as a column
-// of their row is final, so that the next diagonal block is ready when its turn comes.
-template <typename T>
-__device__ __forceinline__ void chain_panel_body(unsigned char* lds, int k, const HostArgs& a) {
-    typedef Tile64<T> TL;
-    const int ld = a.npad, J = a.J, pe = a.pe;
-    T* Mk = (T*)a.M + (size_t)k * a.mat;
-    const T* Wk = (const T*)a.W + (size_t)k * a.mat;
-    T* F = (T*)lds;                        // TS * LD elements (= the four staging buffers of TL::mma)
-    T* Bst = F + TS * TL::LD;              // two B staging buffers behind it
-#pragma unroll 1
-    for (int c = J; c < pe; ++c) {
-        leaf_body<T>(lds, k, (T*)a.M, (T*)a.W, a.mat, a.npad, c, a.logdet, a.info);
-        __syncthreads();                   // L_cc, W_cc stored; the LDS of the diagonal block is free
-#pragma unroll 1
-        for (int r = c + 1; r < pe; ++r) {
-            // (the thread index is taken per tile: taken once in front of the loops, every lane-dependent address of the tile
-            // code is hoisted there and kept alive across the diagonal block, which needs the whole register file itself)
-            const int tid = body_tid(), lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-            const int wm0 = (wave >> 1) * 32, wn0 = (wave & 1) * 32;
-            T* Ct = Mk + (size_t)r * TS * ld + (size_t)c * TS;
-            typename TL::acc_t acc[2][2];
-            T pw[TL::SPT][TL::EPT];
-            TL::fetch(pw, Wk + (size_t)c * TS * ld + (size_t)c * TS, ld, tid);
-            TL::load(acc, Ct, ld, lane, wm0, wn0);
-#pragma unroll 1
-            for (int j = J; j < c; ++j)
-                TL::template mma<true>(acc, Mk + (size_t)r * TS * ld + (size_t)j * TS, ld,
-                                       Mk + (size_t)c * TS * ld + (size_t)j * TS, ld, (T*)lds, tid, lane, wm0, wn0);
-            __syncthreads();               // the staging buffers become F
-            TL::to_operand(acc, F, lane, wm0, wn0);
-            TL::zero(acc);
-            TL::template mma_a_lds<false>(acc, F, pw, Bst, tid, lane, wm0, wn0);
-            TL::store(acc, Ct, ld, lane, wm0, wn0);         // L[r, c]
-            T* Dt = Mk + (size_t)r * TS * ld + (size_t)r * TS;
-            typename TL::acc_t dacc[2][2];
-            TL::load(dacc, Dt, ld, lane, wm0, wn0);
-            __syncthreads();               // every read of the old F has been issued and consumed
-            TL::to_operand(acc, F, lane, wm0, wn0);
-            __syncthreads();
-            TL::template mma_ab_lds<true>(dacc, F, lane, wm0, wn0);
-            TL::store(dacc, Dt, ld, lane, wm0, wn0);
-            __syncthreads();               // F is free; the stores are visible to the workgroup
-        }
-    }
-    // W_PP: pairs of 64-blocks, then the pair of 128-blocks (the bodies of the level-parallel triangular inverse)
-    GemmArgs g;
-    g.sA = g.sB = g.sC = a.mat; g.ldA = g.ldB = g.ldC = ld; g.nb = a.nb;
-    g.q = 1; g.t0 = 0; g.skipq = 1; g.p3 = 0;
-    T* Vk = (T*)a.V + (size_t)k * a.mat;
-#pragma unroll 1
-    for (int mb = 1; mb < pe - J; mb *= 2) {
-        int np = 0;
-        for (int pr = J / (2 * mb); 2 * pr * mb + mb < pe; ++pr) ++np;      // pairs whose second half exists
-        g.p0 = mb; g.p1 = np; g.p2 = J / (2 * mb);
-        g.A = Mk; g.B = Wk; g.C = Vk;
-#pragma unroll 1
-        for (int t = 0; t < np * mb * mb; ++t) {
-            gemm_body<T, OP_TRTRI_T, 64, 4>(g, t, lds);
-            __syncthreads();
-        }
-        g.A = Wk; g.B = Vk; g.C = (void*)Wk;
-#pragma unroll 1
-        for (int t = 0; t < np * mb * mb; ++t) {
-            gemm_body<T, OP_TRTRI_W, 64, 4>(g, t, lds);
-            __syncthreads();
-        }
-    }
-}
-
-template <typename T>
-constexpr int host_lds_bytes() {
-    return host_tile_lds<T>() > LEAF_LDS_BYTES ? host_tile_lds<T>() : LEAF_LDS_BYTES;
-}
-
-template <typename T>
-__global__ __launch_bounds__(HOST_NT, 2) void host_kernel(HostArgs a) {
-    __shared__ __align__(16) unsigned char lds[host_lds_bytes<T>()];
-    if ((int)blockIdx.x < a.nchain) {
-        // waves 4 .. 7 of a chain workgroup leave at once: a barrier only counts the waves that are still running
-        if (threadIdx.x >= 256) return;
-        chain_panel_body<T>(lds, blockIdx.x, a);
-        return;
-    }
-    host_tile_body<T>(a, blockIdx.x - a.nchain, lds);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -2395,17 +2153,13 @@ inline lcgp_sched default_sched() {
     s.progressive_lauum = 48;      // ... and A^-1 = W^T W accumulated behind the chain as well up to this many 64-blocks per side
                                    // (n = 2048: 1.12 -> 0.98 ms; at n = 4096 its tail is one ragged launch of long K loops
                                    // that loses to the one-launch W^T W: 2.54 vs 2.43 ms)
-    s.hosted = 0;                  // 1 = hosted panels (host_kernel): one launch per outer panel whose chain workgroups share it
-                                   // with deferred trailing updates
-    s.hosted_defer = 2;            // ... a column panel receives the finished panels in groups of this many
     return s;
 }
 
 inline int check_sched(const lcgp_sched& s) {
     if (s.outer_blocks < 0 || s.outer_blocks > 64) return bad("sched.outer_blocks must be in [0, 64]");
     if (s.syrk_small_tiles < 0 || s.trtri_small_tiles < 0 || s.lauum_small_tiles < 0 || s.trtri_level_small < 0 ||
-        s.fill_leaf < 0 || s.fill_step < 0 || s.leaf_in_wide < 0 || s.progressive_tiles < 0 || s.progressive_lauum < 0 ||
-        s.hosted < 0 || s.hosted > 2 || s.hosted_defer < 1 || s.hosted_defer > 16)
+        s.fill_leaf < 0 || s.fill_step < 0 || s.leaf_in_wide < 0 || s.progressive_tiles < 0 || s.progressive_lauum < 0)
         return bad("sched fields must be >= 0");
     return 0;
 }
@@ -2460,22 +2214,18 @@ int potrf_trailing(hipStream_t st, const Ws& w, int J, int pe, int c_lo, int c_h
 }
 
 // ---- the plan of a factorisation as a caller-owned, position-independent block of bytes (lcgp_plan_build) ----
-// header | Launch[nlaunch] (the launch-by-launch part) | HostPanel[npanel] (the hosted panels behind it, if any).  It
-// depends on (dtype, n, q_local, with_inverse, sched) only, so a caller builds it once and passes it with every evaluation:
-// no planning in the evaluation loop.
+// header | Launch[nlaunch].  It depends on (dtype, n, q_local, with_inverse, sched) only, so a caller builds it once and
+// passes it with every evaluation: no planning in the evaluation loop.
 constexpr unsigned PLAN_MAGIC = 0x4c43504cu;
 struct PlanHeader {
     unsigned magic;
     int version;
     int dtype, n, nb, q, with_inverse;
-    int nlaunch, npanel;
-    int host_from;             // first block column of the hosted panels (nb: none)
-    int tri_h;                 // > 0: the triangular inverse is part of the plan -- W11 = L11^-1 of the leading tri_h block columns
-                               // in front of the hosted panels, its top-level product T = L21 W11 as hosted tiles, the rest behind
+    int nlaunch;
     int inverse_done;          // what the plan leaves behind the factorisation: 0 = L, 1 = and L^-1, 2 = and A^-1
     int num_cu;
     lcgp_sched sched;
-    size_t off_launch, off_panel, bytes;
+    size_t off_launch, bytes;
 };
 
 inline lcgp_fill::PlanParams plan_params(int dtype, int nb, int q, bool with_inverse, const lcgp_sched& sc, int* inverse_done) {
@@ -2496,66 +2246,34 @@ inline lcgp_fill::PlanParams plan_params(int dtype, int nb, int q, bool with_inv
     return pp;
 }
 
-// first block column of the hosted panels for this shape and schedule (nb: none).  hosted = 1: every panel; hosted = 2: the
-// panels behind the largest power-of-two block count below nb -- the right half of the top level of the triangular inverse,
-// whose product T = L21 W11 then rides on them (only when the inverse follows the factorisation)
-inline int hosted_from(int dtype, int nb, int q, bool with_inverse, const lcgp_sched& sc, int* tri_h) {
-    (void)dtype; (void)q;
-    *tri_h = 0;
-    if (!sc.hosted || !lcgp_fill::HostPlanner::applicable(nb)) return nb;
-    if (sc.hosted == 1) return 0;
-    if (!with_inverse) return nb;
-    int top = 1;
-    while (2 * top < nb) top *= 2;
-    if (top < 8 || nb - top < 8) return nb;        // (at least two hosted panels)
-    *tri_h = top;
-    return top;
-}
-
 // builds the plan into `out` (NULL: only the size is computed) or into `vec` (resized); returns the bytes, 0 on failure
 inline size_t make_plan(int dtype, int n, int q, bool with_inverse, const lcgp_sched& sc, void* out,
                         std::vector<char>* vec = nullptr) {
     const int npad = round_up(n, 2 * TS), nb = npad / TS;
     int inverse_done = 0;
-    lcgp_fill::PlanParams pp = plan_params(dtype, nb, q, with_inverse, sc, &inverse_done);
-    int tri_h = 0;
-    const int hf = hosted_from(dtype, nb, q, with_inverse, sc, &tri_h);
-    if (hf < nb) { pp.stop_block = hf; pp.progressive = false; inverse_done = tri_h > 0 ? 1 : 0; }
-    lcgp_fill::Planner plan(pp);
+    lcgp_fill::Planner plan(plan_params(dtype, nb, q, with_inverse, sc, &inverse_done));
     plan.run();
     if (plan.failed) { bad("internal: the filler queue did not drain"); return 0; }
-    int dev = 0, ncu = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
-        ncu < 1)
-        ncu = 256;
-    (void)hipGetLastError();
-    lcgp_fill::HostPlanner hplan(nb, q, sc.hosted_defer, hf / 4);
-    if (hf < nb) {
-        hplan.tri_h = tri_h;
-        hplan.slots = ncu > q ? ncu - q : 1;
-        hplan.run();
-        if (hplan.failed) { bad("internal: the hosted plan left work behind"); return 0; }
-    }
     PlanHeader h;
     memset(&h, 0, sizeof(h));
     h.magic = PLAN_MAGIC; h.version = LCGP_VERSION;
     h.dtype = dtype; h.n = n; h.nb = nb; h.q = q; h.with_inverse = with_inverse ? 1 : 0;
     h.nlaunch = (int)plan.launches.size();
-    h.npanel = (int)hplan.panels.size();
-    h.host_from = hf;
-    h.tri_h = tri_h;
     h.inverse_done = inverse_done;
     h.sched = sc;
+    int dev = 0, ncu = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
+        ncu < 1)
+        ncu = 256;
+    (void)hipGetLastError();
     h.num_cu = ncu;
     h.off_launch = (sizeof(PlanHeader) + 255) & ~size_t(255);
-    h.off_panel = (h.off_launch + sizeof(lcgp_fill::Launch) * h.nlaunch + 255) & ~size_t(255);
-    h.bytes = (h.off_panel + sizeof(HostPanel) * h.npanel + 255) & ~size_t(255);
+    h.bytes = (h.off_launch + sizeof(lcgp_fill::Launch) * h.nlaunch + 255) & ~size_t(255);
     if (vec) { vec->resize(h.bytes); out = vec->data(); }
     if (out) {
         memset(out, 0, h.bytes);
         memcpy(out, &h, sizeof(h));
         memcpy((char*)out + h.off_launch, plan.launches.data(), sizeof(lcgp_fill::Launch) * h.nlaunch);
-        if (h.npanel) memcpy((char*)out + h.off_panel, hplan.panels.data(), sizeof(HostPanel) * h.npanel);
     }
     return h.bytes;
 }
@@ -2568,58 +2286,6 @@ inline int check_plan(const void* plan_host, int dtype, int n, int q, bool with_
     return 0;
 }
 
-template <typename T>
-int do_trtri_part(hipStream_t st, const Ws& w, const lcgp_sched& sc, int mb_lo, int mb_hi, int b_lo, int b_hi, int which);
-
-// Hosted panels (see host_kernel): per outer panel the launch that factors its diagonal block beside deferred trailing
-// updates, the panel solve of the rows below and the rank-256 update of the next panel's columns.
-template <typename T>
-int do_potrf_hosted(hipStream_t st, const Ws& w, const HostPanel* panels, int npanel) {
-    T* M = (T*)(w.base + w.off_M);
-    T* W = (T*)(w.base + w.off_W);
-    T* V = (T*)(w.base + w.off_V);
-    for (int pi = 0; pi < npanel; ++pi) {
-        const HostPanel& p = panels[pi];
-        HostArgs a;
-        a.M = M; a.W = W; a.V = V; a.mat = w.mat; a.npad = w.npad; a.nb = w.nb; a.q = w.q;
-        a.J = p.J; a.pe = p.pe;
-        a.nchain = p.J >= 0 ? w.q : 0;
-        a.logdet = (double*)(w.base + w.off_logdet); a.info = (int*)(w.base + w.off_info);
-        a.njobs = p.njobs;
-        memcpy(a.job, p.job, sizeof(a.job));
-        if (a.nchain + p.nhost > 0) {
-            hipLaunchKernelGGL((host_kernel<T>), dim3((unsigned)(a.nchain + p.nhost)), dim3(HOST_NT), 0, st, a);
-            CHECK_LAUNCH("host_kernel");
-        }
-        if (p.ne == p.pe) continue;        // the last panel, or a launch of hosted tiles only
-        // the rows below: L[R, panel] = X[R, panel] W_PP^T
-        GemmArgs g;
-        g.sA = g.sB = g.sC = w.mat; g.ldA = g.ldB = g.ldC = w.npad;
-        g.B = W; g.C = M; g.nb = w.nb; g.p0 = p.J; g.p2 = p.pe; g.q = w.q; g.t0 = 0; g.skipq = 1;
-        const int rows = w.nb - p.pe;
-        if (pi == 0) {         // the first hosted panel sits in M: in place, block column by block column from the right
-            g.A = M; g.p3 = 0;
-            for (int jt = p.pe - p.J - 1; jt >= 0; --jt) {
-                g.p1 = jt;
-                hipLaunchKernelGGL((tile_gemm<T, OP_PSOLVE, 64, 4>), dim3((unsigned)rows * w.q), dim3(256), 0, st, g);
-                CHECK_LAUNCH("tile_gemm");
-            }
-        } else {
-            g.A = V; g.p1 = 0; g.p3 = p.pe - p.J;
-            hipLaunchKernelGGL((tile_gemm<T, OP_PSOLVE, 64, 4>), dim3((unsigned)rows * g.p3 * w.q), dim3(256), 0, st, g);
-            CHECK_LAUNCH("tile_gemm");
-        }
-        // the next panel's columns receive this panel: diagonal block back into M, the rows below it into V
-        GemmArgs u;
-        u.sA = u.sB = u.sC = w.mat; u.ldA = u.ldB = u.ldC = w.npad;
-        u.A = M; u.B = M; u.C = M; u.nb = w.nb; u.p0 = p.J; u.p1 = p.pe; u.p2 = p.pe; u.p3 = p.ne;
-        u.C2 = V; u.r_c2 = p.ne;
-        const int rc = launch_gemm<T, OP_SYRK>(st, u, trapezoid_tiles(w.nb, p.pe, p.ne), w.q);
-        if (rc) return rc;
-    }
-    return 0;
-}
-
 // Two-level right-looking Cholesky.  Outer panels of `ob` 64-blocks: inside a panel every 64-column step is ONE launch
 // (chain_step_kernel) that only touches the panel's block column and the rest of the panel; the trailing matrix is read
 // and written once per outer panel with K = 64 ob.  The trailing update of panel J is split by columns into one wide
@@ -2627,8 +2293,7 @@ int do_potrf_hosted(hipStream_t st, const Ws& w, const HostPanel* panels, int np
 // launches of panel J+1 carry as filler tiles -- the chain leaves >= 97 % of the CUs idle, and a second HIP stream
 // cannot fill them on this platform.  The launch sequence is PLANNED first (fill_sched.h: Planner, host
 // only, replayed on the CPU by tests/test_fill_sched.py through tests/native/dump_plan.cpp) -- by the caller, once
-// (lcgp_plan_build), or here per call when no plan is passed -- and then enqueued launch by launch; the hosted panels
-// of the plan (if any) follow.
+// (lcgp_plan_build), or here per call when no plan is passed -- and then enqueued launch by launch.
 template <typename T>
 int do_potrf(hipStream_t st, const Ws& w, const lcgp_sched& sc, bool stats_zeroed = false, bool with_inverse = false,
              int* inverse_done = nullptr /* 0 = nothing, 1 = L^-1, 2 = L^-1 and A^-1 */, const void* plan_host = nullptr) {
@@ -2687,18 +2352,6 @@ int do_potrf(hipStream_t st, const Ws& w, const lcgp_sched& sc, bool stats_zeroe
         }
         if (rc) return rc;
     }
-    if (h->npanel > 0) {
-        int rc = 0;
-        // the inverse as part of the plan: W11 = L11^-1 (every level below the top one) in front of the hosted panels, which
-        // carry the top-level product T = L21 W11; behind them the levels of the trailing part (the chains have left the
-        // first two) and W21 = -W22 T
-        if (h->tri_h > 0 && (rc = do_trtri_part<T>(st, w, h->sched, 1, h->tri_h, 0, h->tri_h, 0))) return rc;
-        if ((rc = do_potrf_hosted<T>(st, w, (const HostPanel*)((const char*)plan_host + h->off_panel), h->npanel))) return rc;
-        if (h->tri_h > 0) {
-            if ((rc = do_trtri_part<T>(st, w, h->sched, 4, h->tri_h, h->tri_h, 0, 0))) return rc;
-            if ((rc = do_trtri_part<T>(st, w, h->sched, h->tri_h, 2 * h->tri_h, 0, 0, 2))) return rc;
-        }
-    }
     return 0;
 }
 
@@ -2710,55 +2363,37 @@ inline bool use_small_tiles(const Ws& w, int threshold) {
     return (long long)w.q * (nb2 * (nb2 + 1) / 2) < threshold;
 }
 
-// one level of the triangular inverse: pairs of blocks of mb tiles (TM units), the pairs [p_lo, p_hi) (p_hi < 0: all);
-// which: 0 = T = L21 W11 and W21 = -W22 T, 1 = T only, 2 = W21 only (T is in V already)
 template <typename T, int TM>
-int trtri_level(hipStream_t st, const Ws& w, int mb, int p_lo = 0, int p_hi = -1, int which = 0) {
+int trtri_level(hipStream_t st, const Ws& w, int mb) {      // one level: pairs of blocks of mb tiles (TM units)
     GemmArgs g;
-    g.sA = g.sB = g.sC = w.mat; g.ldA = g.ldB = g.ldC = w.npad; g.p3 = 0;
+    g.sA = g.sB = g.sC = w.mat; g.ldA = g.ldB = g.ldC = w.npad; g.p2 = g.p3 = 0;
     const int nbt = w.npad / TM;
     g.nb = nbt;
-    const int all = (nbt + 2 * mb - 1) / (2 * mb);
-    if (p_hi < 0 || p_hi > all) p_hi = all;
-    const int pairs = p_hi - p_lo;
-    if (pairs <= 0) return 0;
-    g.p0 = mb; g.p1 = pairs; g.p2 = p_lo;
-    int rc = 0;
-    if (which != 2) {
-        g.A = (T*)(w.base + w.off_M); g.B = (T*)(w.base + w.off_W); g.C = (T*)(w.base + w.off_V);
-        rc = launch_gemm<T, OP_TRTRI_T, TM>(st, g, pairs * mb * mb, w.q);
-        if (rc) return rc;
-    }
-    if (which != 1) {
-        g.A = (T*)(w.base + w.off_W); g.B = (T*)(w.base + w.off_V); g.C = (T*)(w.base + w.off_W);
-        rc = launch_gemm<T, OP_TRTRI_W, TM>(st, g, pairs * mb * mb, w.q);
-    }
-    return rc;
+    const int pairs = (nbt + 2 * mb - 1) / (2 * mb);
+    g.p0 = mb; g.p1 = pairs;
+    g.A = (T*)(w.base + w.off_M); g.B = (T*)(w.base + w.off_W); g.C = (T*)(w.base + w.off_V);
+    int rc = launch_gemm<T, OP_TRTRI_T, TM>(st, g, pairs * mb * mb, w.q);
+    if (rc) return rc;
+    g.A = (T*)(w.base + w.off_W); g.B = (T*)(w.base + w.off_V); g.C = (T*)(w.base + w.off_W);
+    return launch_gemm<T, OP_TRTRI_W, TM>(st, g, pairs * mb * mb, w.q);
 }
 
-// The levels mb64 = mb_lo, 2 mb_lo, .. < mb_hi of W = L^-1 (64-block units: mb64 = 1 joins pairs of 64-blocks) for the pairs
-// that lie in the block range [b_lo, b_hi) (b_hi <= 0: to the end); mb64 = 1 always on 64x64 tiles, a further level on
-// 128x128 tiles unless the whole inverse or the whole level is too small to fill the chip with them.
 template <typename T>
-int do_trtri_part(hipStream_t st, const Ws& w, const lcgp_sched& sc, int mb_lo, int mb_hi, int b_lo, int b_hi, int which) {
+int do_trtri(hipStream_t st, const Ws& w, const lcgp_sched& sc) {
     const bool all_small = use_small_tiles(w, sc.trtri_small_tiles);
-    for (int mb64 = mb_lo; mb64 < mb_hi && mb64 < w.nb; mb64 *= 2) {
+    // levels in 64-block units: mb64 = 1 joins pairs of 64-blocks (always 64x64 tiles); a further level works on 128x128
+    // tiles unless the whole inverse or this level is too small to fill the chip with them
+    for (int mb64 = 1; mb64 < w.nb; mb64 *= 2) {
         bool small = all_small || mb64 == 1;
         if (!small) {
             const int mb = mb64 / 2, nbt = w.npad / 128;
             const long long tiles = (long long)((nbt + 2 * mb - 1) / (2 * mb)) * mb * mb * w.q;
             small = tiles < sc.trtri_level_small;
         }
-        const int p_lo = b_lo / (2 * mb64), p_hi = b_hi > 0 ? b_hi / (2 * mb64) : -1;
-        const int rc = small ? trtri_level<T, 64>(st, w, mb64, p_lo, p_hi, which) : trtri_level<T, 128>(st, w, mb64 / 2, p_lo, p_hi, which);
+        const int rc = small ? trtri_level<T, 64>(st, w, mb64) : trtri_level<T, 128>(st, w, mb64 / 2);
         if (rc) return rc;
     }
     return 0;
-}
-
-template <typename T>
-int do_trtri(hipStream_t st, const Ws& w, const lcgp_sched& sc) {
-    return do_trtri_part<T>(st, w, sc, 1, w.nb, 0, 0, 0);
 }
 
 template <typename T>
@@ -3156,12 +2791,11 @@ int lcgp_plan_build(int dtype, int n, int q_local, int with_inverse, const lcgp_
     return make_plan(dtype, n, q_local, with_inverse != 0, sc, plan) ? 0 : -1;
 }
 
-int lcgp_plan_info(const void* plan, int* nlaunch, int* npanel, int* inverse_done) {
+int lcgp_plan_info(const void* plan, int* nlaunch, int* inverse_done) {
     if (!plan) return bad("plan is NULL");
     const PlanHeader* h = (const PlanHeader*)plan;
     if (h->magic != PLAN_MAGIC || h->version != LCGP_VERSION) return bad("plan: not a plan of this library version");
     if (nlaunch) *nlaunch = h->nlaunch;
-    if (npanel) *npanel = h->npanel;
     if (inverse_done) *inverse_done = h->inverse_done;
     return 0;
 }

@@ -122,16 +122,16 @@ class HotPathEngine:
         return C.c_void_p(self._plan_cache[key].ctypes.data)
 
     def plan_info(self, with_inverse=True):
-        """launches / hosted panels / what the plan leaves behind the factorisation (lcgp_plan_info)"""
+        """launches / what the plan leaves behind the factorisation (lcgp_plan_info)"""
         key = bool(with_inverse)
         host = self._plan_cache.get(key) if self.use_plan else None
         if host is None:
             host = self._build_plan(key)        # (use_plan = False: a temporary plan, what the library would plan per call)
             if self.use_plan:
                 self._plan_cache[key] = host
-        v = [C.c_int(0) for _ in range(3)]
+        v = [C.c_int(0) for _ in range(2)]
         _hip.check(self.lib.lcgp_plan_info(C.c_void_p(host.ctypes.data), *[C.byref(x) for x in v]), "lcgp_plan_info")
-        return dict(zip(("launches", "hosted_panels", "inverse_done"), (x.value for x in v)))
+        return dict(zip(("launches", "inverse_done"), (x.value for x in v)))
 
     def upload_theta(self, theta_rows, guard=0.0, stream=None):
         torch = self.torch

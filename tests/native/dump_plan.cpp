@@ -1,9 +1,7 @@
-// Prints the launch plan of one factorisation (lcgp_amd/csrc/fill_sched.h: Planner, HostPlanner) as text, for the CPU
-// replay in tests/test_fill_sched.py.  Host-only: g++ -std=c++17 -I lcgp_amd/csrc tests/native/dump_plan.cpp
-//   usage: dump_plan nb q ob syrk_small_tiles fill_leaf fill_step leaf_in_wide progressive [far_rides [with_dupd [host_from [defer]]]]
-// One line per launch ("L key=value ..."), followed by its filler jobs ("J ...").  host_from >= 0: the launch-by-launch plan
-// stops in front of that block column and the hosted panels follow, one line per panel ("H ...") followed by its
-// deferred-update jobs ("U ...").
+// Prints the launch plan of one factorisation (lcgp_amd/csrc/fill_sched.h: Planner) as text, for the CPU replay in
+// tests/test_fill_sched.py.  Host-only: g++ -std=c++17 -I lcgp_amd/csrc tests/native/dump_plan.cpp
+//   usage: dump_plan nb q ob syrk_small_tiles fill_leaf fill_step leaf_in_wide progressive [far_rides [with_dupd]]
+// One line per launch ("L key=value ..."), followed by its filler jobs ("J ...").
 #include <cstdio>
 #include <cstdlib>
 
@@ -14,16 +12,13 @@ static void print_job(const lcgp_fill::FillJob& j) {
 }
 
 int main(int argc, char** argv) {
-    if (argc < 9 || argc > 13) { fprintf(stderr, "usage: dump_plan nb q ob syrk_small fill_leaf fill_step leaf_in_wide progressive\n"); return 2; }
+    if (argc < 9 || argc > 11) { fprintf(stderr, "usage: dump_plan nb q ob syrk_small fill_leaf fill_step leaf_in_wide progressive\n"); return 2; }
     lcgp_fill::PlanParams pp;
     pp.nb = atoi(argv[1]); pp.q = atoi(argv[2]); pp.ob = atoi(argv[3]); pp.syrk_small_tiles = atoi(argv[4]);
     pp.fill_leaf = atoi(argv[5]); pp.fill_step = atoi(argv[6]); pp.leaf_in_wide = atoi(argv[7]);
     pp.progressive = atoi(argv[8]) != 0;
     pp.far_rides = argc > 9 ? atoi(argv[9]) != 0 : true;
     pp.with_dupd = argc > 10 ? atoi(argv[10]) != 0 : true;
-    const int host_from = argc > 11 ? atoi(argv[11]) : -1;
-    const int defer = argc > 12 ? atoi(argv[12]) : 2;
-    if (host_from >= 0) { pp.stop_block = host_from; pp.progressive = false; }
     lcgp_fill::Planner plan(pp);
     plan.run();
     if (plan.failed) { printf("FAILED\n"); return 1; }
@@ -35,18 +30,6 @@ int main(int argc, char** argv) {
             printf("J");
             print_job(l.fs.job[i]);
             printf("\n");
-        }
-    }
-    if (host_from >= 0) {
-        if (!lcgp_fill::HostPlanner::applicable(pp.nb) || host_from % 4) { printf("FAILED\n"); return 1; }
-        lcgp_fill::HostPlanner hp(pp.nb, pp.q, defer, host_from / 4);
-        hp.run();
-        if (hp.failed) { printf("FAILED\n"); return 1; }
-        for (const lcgp_fill::HostPanel& p : hp.panels) {
-            printf("H J=%d pe=%d ne=%d njobs=%d nhost=%d\n", p.J, p.pe, p.ne, p.njobs, p.nhost);
-            for (int i = 0; i < p.njobs; ++i)
-                printf("U cp0=%d ncp=%d k0=%d k1=%d np=%d nblk=%d\n", p.job[i].cp0, p.job[i].ncp, p.job[i].k0, p.job[i].k1, p.job[i].np,
-                       p.job[i].nblk);
         }
     }
     return 0;

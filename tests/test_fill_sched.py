@@ -23,29 +23,23 @@ def dump_plan(tmp_path_factory):
     subprocess.run(['g++', '-std=c++17', '-O1', '-I', os.path.join(ROOT, 'lcgp_amd', 'csrc'), '-o', exe,
                     os.path.join(ROOT, 'tests', 'native', 'dump_plan.cpp')], check=True)
 
-    def run(nb, q, ob, syrk_small=2000, fill_leaf=248, fill_step=248, leaf_in_wide=1024, progressive=1, far_rides=1, with_dupd=1,
-            host_from=-1, defer=2):
+    def run(nb, q, ob, syrk_small=2000, fill_leaf=248, fill_step=248, leaf_in_wide=1024, progressive=1, far_rides=1, with_dupd=1):
         out = subprocess.run([exe] + [str(v) for v in (nb, q, ob, syrk_small, fill_leaf, fill_step, leaf_in_wide, progressive,
-                                                       far_rides, with_dupd, host_from, defer)],
+                                                       far_rides, with_dupd)],
                              check=True, capture_output=True, text=True).stdout
         assert 'FAILED' not in out
-        launches, panels = [], []
+        launches = []
         for line in out.splitlines():
             f = line.split()
             d = {k: int(v) for k, _, v in (kv.partition('=') for kv in f[1:])}
             if f[0] == 'L':
                 d['jobs'] = []
                 launches.append(d)
-            elif f[0] == 'J':
+            else:
+                assert f[0] == 'J'
                 d['t0'] = d.pop('jt0')
                 launches[-1]['jobs'].append(d)
-            elif f[0] == 'H':
-                d['jobs'] = []
-                panels.append(d)
-            else:
-                assert f[0] == 'U'
-                panels[-1]['jobs'].append(d)
-        return (launches, panels) if host_from >= 0 else launches
+        return launches
     return run
 
 
@@ -229,79 +223,6 @@ class Replay:
             self.run_jobs(l)
             self.end_launch()
 
-    # ---- hosted panels (host_kernel, the out-of-place panel solve, the next-panel update): three launches per panel ----
-    def run_hosted(self, panels):
-        nb, q = self.nb, self.q
-        nan = np.full((TS, TS), np.nan)
-        for pi, p in enumerate(panels):
-            J, pe, ne = p['J'], p['pe'], p['ne']
-            # A: one chain workgroup factors and inverts the whole diagonal block; deferred updates beside it
-            self.begin_launch()
-            self.new_item()
-            m = pe - J
-            blk = np.zeros((m * TS, m * TS))
-            for r in range(m):
-                for c in range(r + 1):
-                    blk[r * TS:(r + 1) * TS, c * TS:(c + 1) * TS] = self.rd('M', J + r, J + r + 1, J + c, J + c + 1)
-            blk = np.tril(blk) + np.tril(blk, -1).T
-            Lb = np.linalg.cholesky(blk)
-            Wb = np.tril(np.linalg.inv(Lb))
-            self.wr('St', 0, 0, self.rd('St', 0, 1, 0, 1) + 1.0 * m)
-            for r in range(m):
-                for c in range(r + 1):
-                    self.wr('M', J + r, J + c, Lb[r * TS:(r + 1) * TS, c * TS:(c + 1) * TS])
-                    self.wr('W', J + r, J + c, Wb[r * TS:(r + 1) * TS, c * TS:(c + 1) * TS])
-                    if c < r:
-                        self.wr('V', J + r, J + c, nan)             # scratch of the block inverse
-                if (J + r) % 2 == 0 and J + r + 1 < nb:
-                    self.wr('W', J + r, J + r + 1, np.zeros((TS, TS)))
-            nblk = 0
-            for jb in p['jobs']:
-                assert jb['np'] * 4 == nb and 0 <= jb['k0'] < jb['k1'] <= J
-                ntile = 0
-                for cp in range(jb['cp0'], jb['cp0'] + jb['ncp']):
-                    assert cp > J // 4
-                    for R in range(cp, jb['np']):
-                        for h in range(2):
-                            self.new_item()
-                            ntile += 1
-                            for cc in range(4 * cp + 2 * h, 4 * cp + 2 * h + 2):
-                                for rr in range(4 * R, 4 * R + 4):
-                                    if rr < cc:
-                                        # above the diagonal: the kernel rewrites such a block too (rows 0 .. 127 of the second
-                                        # column tile excepted) -- nobody may read it
-                                        if not (h == 1 and rr < 4 * cp + 2):
-                                            self.wr('M', rr, cc, nan)
-                                        continue
-                                    t = self.rd('M', rr, rr + 1, cc, cc + 1) - \
-                                        self.rd('M', rr, rr + 1, jb['k0'], jb['k1']) @ self.rd('M', cc, cc + 1, jb['k0'], jb['k1']).T
-                                    self.wr('M', rr, cc, t)
-                assert jb['nblk'] == ntile * q
-                nblk += jb['nblk']
-            assert nblk == p['nhost']
-            self.end_launch()
-            if ne == pe:
-                break
-            # B: the rows below, L[R, panel] = X[R, panel] W_PP^T -- out of place from V; the first hosted panel sits in M and is
-            # solved in place, one launch per block column from the right
-            src = 'M' if pi == 0 else 'V'
-            for group in ([[jt] for jt in range(m - 1, -1, -1)] if pi == 0 else [list(range(m - 1, -1, -1))]):
-                self.begin_launch()
-                for jt in group:
-                    for R in range(pe, nb):
-                        self.new_item()
-                        v = self.rd(src, R, R + 1, J, J + jt + 1) @ self.rd('W', J + jt, J + jt + 1, J, J + jt + 1).T
-                        self.wr('M', R, J + jt, v)
-                self.end_launch()
-            # C: the next panel's columns receive this panel; its diagonal block stays in M, the rows below go to V
-            self.begin_launch()
-            for C in range(pe, ne):
-                for r in range(C, nb):
-                    self.new_item()
-                    t = self.rd('M', r, r + 1, C, C + 1) - self.rd('M', r, r + 1, J, pe) @ self.rd('M', C, C + 1, J, pe).T
-                    self.wr('M' if r < ne else 'V', r, C, t)
-            self.end_launch()
-
     def check(self, inverse, ainv=True):
         L = np.linalg.cholesky(self.A)
         n = L.shape[0]
@@ -377,42 +298,3 @@ def test_filler_capacity_is_respected(dump_plan):
                 assert l['nblk'] <= 248
                 assert len(l['jobs']) <= 6
 
-
-HOSTED = [(64, 8, 0, 2), (64, 8, 0, 1), (64, 8, 0, 4), (64, 1, 0, 2), (16, 4, 0, 2), (32, 6, 0, 3), (8, 1, 0, 2), (12, 2, 0, 2),
-          (64, 8, 32, 2), (64, 4, 48, 2), (32, 6, 16, 1), (16, 2, 8, 2), (16, 2, 12, 2), (72, 2, 36, 16)]
-
-
-@pytest.mark.parametrize('nb,q,host_from,defer', HOSTED)
-def test_hosted_panels_replay_to_the_factor(dump_plan, nb, q, host_from, defer):
-    """lcgp_sched.hosted: the launch-by-launch plan up to block column `host_from` (0: none), then per panel the launch that
-    factors its whole diagonal block beside deferred trailing updates, the panel solve and the next-panel update"""
-    launches, panels = dump_plan(nb, q, 4, progressive=0, host_from=host_from, defer=defer)
-    assert len(panels) == (nb - host_from) // 4
-    assert all(l['pe'] <= host_from for l in launches)
-    r = Replay(nb, q, seed=7 * nb + q)
-    r.run(launches)
-    r.run_hosted(panels)
-    r.check(inverse=False)
-    # every column panel receives every finished panel exactly once (the deferred jobs + the next-panel updates)
-    np_ = nb // 4
-    seen = {c: [] for c in range(np_)}
-    for p in panels:
-        for jb in p['jobs']:
-            for c in range(jb['cp0'], jb['cp0'] + jb['ncp']):
-                seen[c] += list(range(jb['k0'] // 4, jb['k1'] // 4))
-        if p['ne'] > p['pe']:
-            seen[p['pe'] // 4].append(p['J'] // 4)
-    for c in range(host_from // 4 + 1, np_):
-        assert sorted(seen[c]) == list(range(host_from // 4, c)), c
-
-
-def test_hosted_replay_catches_a_missing_contribution(dump_plan):
-    launches, panels = dump_plan(32, 2, 4, progressive=0, host_from=0, defer=2)
-    victim = next(p for p in panels if p['jobs'])
-    victim['nhost'] -= victim['jobs'][-1]['nblk']
-    victim['jobs'].pop()
-    r = Replay(32, 2, seed=1)
-    r.run(launches)
-    r.run_hosted(panels)
-    with pytest.raises(AssertionError):
-        r.check(inverse=False)

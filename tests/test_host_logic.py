@@ -396,28 +396,23 @@ def test_launch_plan_is_built_once_by_the_caller():
         assert lib.lcgp_plan_bytes(0, n, q, inv, C.byref(sc), C.byref(nb)) == 0
         buf = np.zeros(nb.value, np.uint8)
         assert lib.lcgp_plan_build(0, n, q, inv, C.byref(sc), C.c_void_p(buf.ctypes.data), nb) == 0
-        v = [C.c_int(0) for _ in range(3)]
+        v = [C.c_int(0) for _ in range(2)]
         assert lib.lcgp_plan_info(C.c_void_p(buf.ctypes.data), *[C.byref(t) for t in v]) == 0
         return buf, [t.value for t in v]
     a, ia = build(4096, 8, 1)
     b, ib = build(4096, 8, 1)
-    assert ia == ib and ia[0] > 60 and ia[1] == 0 and ia[2] == 0      # launches; no hosted panels; nothing of the inverse behind
-                                                                       # the factorisation at q = 8
+    assert ia == ib and ia[0] > 60 and ia[1] == 0          # launches; nothing of the inverse behind the factorisation at q = 8
     # (the bytes differ only where the header records the device's compute-unit count, identical here)
     assert np.array_equal(a, b)
     _, i1 = build(4096, 1, 1)
-    assert i1[2] == 1                                      # one component per rank: L^-1 behind the chain
-    _, i2 = build(4096, 8, 1, hosted=1)
-    assert i2[0] == 0 and i2[1] == 16 and i2[2] == 0       # hosted panels: one entry per 256-column panel, no launch list
-    _, i3 = build(4000, 8, 1, hosted=1)
-    assert i3[1] == 16                                     # (n is padded to 4096)
-    _, i4 = build(4096 - 128, 8, 1, hosted=1)
-    assert i4[1] == 0 and i4[0] > 60                       # not a multiple of 256 after padding: the launch-by-launch plan
+    assert i1[1] == 1                                      # one component per rank: L^-1 behind the chain
+    _, i2 = build(4096, 8, 1, fill_leaf=0, fill_step=0)
+    assert i2[0] != ia[0]                                  # the schedule is part of the plan
     nb = C.c_size_t(0)
     assert lib.lcgp_plan_build(0, 4096, 8, 1, None, C.c_void_p(a.ctypes.data), C.c_size_t(16)) < 0
     assert b'too small' in lib.lcgp_last_error()
     junk = np.zeros(512, np.uint8)
-    assert lib.lcgp_plan_info(C.c_void_p(junk.ctypes.data), None, None, None) < 0
+    assert lib.lcgp_plan_info(C.c_void_p(junk.ctypes.data), None, None) < 0
 
 
 def test_native_library_is_the_one_built_from_these_sources():
