@@ -74,7 +74,13 @@ def stage_times(m, reps=3):
         torch.cuda.synchronize(eng.device)
         for i, k in enumerate(names):
             acc[k].append(ev[i].elapsed_time(ev[i + 1]))
-    return {k: float(np.median(v)) for k, v in acc.items()}
+    out = {k: float(np.median(v)) for k, v in acc.items()}
+    # the clock the chip held during the last A^-1 launch above (un-profiled): its first workgroup stamps its K loop with the
+    # shader-clock counter and the 100 MHz real-time counter (lcgp_lauum_clock)
+    clk = torch.zeros(2, dtype=torch.int64, device=eng.device)
+    _hip.check(lib.lcgp_lauum_clock(sp, *args, ws, C.c_void_p(clk.data_ptr())), 'lauum_clock')
+    cyc, ticks = (int(v) for v in clk.cpu())
+    return out, dict(clock_mhz=100.0 * cyc / ticks if ticks > 0 else None, clock_window_us=ticks / 100.0)
 
 
 def predict_leg(m, n0, reps=5):
@@ -274,9 +280,10 @@ def main():
         mine['device_name'] = 'unknown (%s)' % e
     if not args.no_stages:
         m.loss_and_grad(pts[0])          # collective: every rank takes part (leaves theta_0 resident)
-    st = None
+    st = clock = None
     if not args.no_stages and m._engine is not None:
-        st = stage_times(m)
+        st, clock = stage_times(m)
+        mine['lauum_clock'] = clock
         esz = 8 if dtype == 'float64' else 4
         mine['stages_ms'] = st
         mine['stage_tflops'] = {k: ql * n ** 3 / 3.0 / (st[k] * 1e-3) / 1e12 for k in ('potrf', 'trtri', 'lauum')}
@@ -341,18 +348,20 @@ def main():
         del mf
 
     if rank == 0 and st is not None:
-        log('stages (ms): %s' % st)
+        clock_mhz, clock_window_us = clock['clock_mhz'], clock['clock_window_us']
+        log('stages (ms): %s; shader clock during A^-1 = W^T W: %s MHz over %s us' % (st, clock_mhz and round(clock_mhz), clock_window_us))
         out['stages_ms'] = st
         # dominant kernel: the single-launch LAUUM (tile_gemm<OP_LAUUM>): A^-1 = W^T W, n^3/3 flops per component
         fl = ql * float(n) ** 3 / 3.0
         # HBM-side bytes of that launch come from separate rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; MI355X guide),
         # summarised in profiles/traffic.json together with the source hash of the library they were measured on:
         # a number measured on another build of the kernels is NOT reported
-        traffic = None
+        traffic = mfma_busy = None
         try:
             tj = json.load(open(os.path.join(ROOT, 'profiles', 'traffic.json')))
             if world == 1 and args.config == 3 and args.n is None and args.q is None and tj.get('lib_hash') == _hip.loaded_hash():
                 traffic = tj.get('tile_gemm_lauum_bytes_per_launch')
+                mfma_busy = tj.get('tile_gemm_lauum_mfma_busy')
         except Exception:
             pass
         sched = _hip.default_sched()
@@ -363,6 +372,12 @@ def main():
                                achieved=fl / (st['lauum'] * 1e-3) / 1e12, peak=peak, unit='TFLOP/s',
                                frac=fl / (st['lauum'] * 1e-3) / 1e12 / peak, traffic=traffic,
                                flops_per_launch=fl, launch_ms=st['lauum'],
+                               clock_mhz=clock_mhz, clock_window_us=clock_window_us,
+                               clock_note='shader-clock cycles / real time of the longest K loop of THIS run\'s last A^-1 launch '
+                                          '(in-kernel s_memtime / s_memrealtime, un-profiled); the 78.6 TFLOP/s peak is 256 CUs x 128 flop/cycle x 2400 MHz',
+                               mfma_busy=mfma_busy,
+                               mfma_busy_note='SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8) of this kernel from the '
+                                              'rocprofv3 --pmc pass in profiles/ (same library hash), or null',
                                launched_by_the_timed_path=not progressive,
                                note=None if not progressive else
                                'with %d component(s) on this rank the timed path forms the inverse behind the factorisation '

@@ -122,6 +122,14 @@ int lcgp_potri(void* stream, int dtype, int n, int d, int p, int q_local, void* 
 int lcgp_trtri(void* stream, int dtype, int n, int d, int p, int q_local, void* workspace, const lcgp_sched* sched);
 int lcgp_lauum(void* stream, int dtype, int n, int d, int p, int q_local, void* workspace, const lcgp_sched* sched);
 
+/* Measurement support (no counterpart in the reference): the first workgroup of the one-launch A^-1 = W^T W (lcgp_lauum, and
+ * the same launch inside lcgp_nll_grad, on 128x128 tiles) stamps its K loop -- the longest of the launch -- with the
+ * shader-clock counter and with the 100 MHz real-time counter; this copies the two durations of the LAST such launch to
+ * `out` (device, 2 x 64 bit: shader cycles, 10 ns ticks).  cycles / ticks x 100 = the clock in MHz the chip held while the
+ * fp64 MFMA pipe was loaded, measured in the un-profiled path (bench.py: roofline.clock_mhz). */
+int lcgp_lauum_clock(void* stream, int dtype, int n, int d, int p, int q_local, const void* workspace,
+                     unsigned long long* out /*device, 2 words*/);
+
 /* copies matrix `which` (0 = A/L, 1 = L^-1, 2 = A^-1) of local component k out of the workspace as a
  * dense n x n row-major matrix (lower triangle valid, upper triangle mirrored); for tests. */
 int lcgp_fetch_matrix(void* stream, int dtype, int n, int d, int p, int q_local, const void* workspace,

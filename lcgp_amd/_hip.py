@@ -46,6 +46,7 @@ SIGNATURES = {
     "lcgp_potri": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _sp]),
     "lcgp_trtri": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _sp]),
     "lcgp_lauum": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _sp]),
+    "lcgp_lauum_clock": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "lcgp_fetch_matrix": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _i, _i, _vp]),
     "lcgp_fetch_vector": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _i, _i, _vp]),
     "lcgp_nll_grad": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _sp, _vp]),

@@ -56,7 +56,7 @@ struct Ws {
     size_t esz;
     size_t mat;          // elements per matrix
     char* base;
-    size_t off_M, off_W, off_V, off_b, off_z, off_part, off_cpart, off_c, off_logdet, off_info, total;
+    size_t off_M, off_W, off_V, off_b, off_z, off_part, off_cpart, off_c, off_logdet, off_info, off_clock, total;
     int ntile_lower;
 };
 
@@ -84,6 +84,7 @@ inline Ws carve(int dtype, int n, int d, int p, int q, void* base) {
     w.off_c = o; o = align256(o + (dtype == LCGP_F64 ? 0 : (size_t)w.npad * q * sizeof(double)));
     w.off_logdet = o; o = align256(o + (size_t)q * sizeof(double));
     w.off_info = o; o = align256(o + (size_t)q * sizeof(int));
+    w.off_clock = o; o = align256(o + 4 * sizeof(unsigned long long));     // shader-clock / real-time stamps of the last A^-1 launch
     w.total = o;
     return w;
 }
@@ -669,6 +670,8 @@ struct GemmArgs {
                                                 // (the diagonal block there is factored by the same launch, wide_leaf_kernel)
     const void* bvec = nullptr;                 // OP_LAUUM on 128-tiles: b (npad per component) and the partial buffer of
     double* part = nullptr;                     // z = A^-1 b, [component][tile][2][128]; null = no fused product
+    unsigned long long* clk = nullptr;          // OP_LAUUM: the first block (the longest K loop of the launch) leaves its duration
+                                                // in shader-clock cycles and in 10 ns ticks here: the clock the chip held (lcgp_lauum_clock)
 };
 
 // one K-stage (KT = 16 k values) of a TM-row operand tile: global -> registers -> LDS [k][m], ld = TM + 16;
@@ -878,6 +881,12 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, const int lin /*blo
 
     constexpr int SPT = TM / KT;   // stages per k tile
     const int nst = nkt * SPT;
+    // (measurement support: the first block of the one-launch A^-1 = W^T W has the longest K loop of the launch; wave 0 stamps it
+    // with the shader-clock counter and the 100 MHz real-time counter, both scalar: the ratio is the clock the chip held)
+    unsigned long long clk0 = 0, rt0 = 0;
+    if constexpr (OP == OP_LAUUM && TM == 128) {
+        if (g.clk && lin == 0 && wave == 0) { clk0 = __builtin_amdgcn_s_memtime(); rt0 = __builtin_amdgcn_s_memrealtime(); }
+    }
     // The LAST k tile of the triangular products holds a triangular TM x TM block of W (LAUUM: W[r,r] as A, and as B too
     // on a diagonal tile; TRTRI_T: W11[cl,cl] as B; TRTRI_W: W22[rl,rl] as A; PRED_U: W[r,r] as B).  In the stage that
     // covers its k rows [ks, ks + 16) a wave whose rows (columns) of that operand lie wholly on the zero side would
@@ -991,6 +1000,12 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, const int lin /*blo
                     *dst = (T)v;
                 }
             }
+    if constexpr (OP == OP_LAUUM && TM == 128) {
+        if (g.clk && lin == 0 && wave == 0) {
+            const unsigned long long c1 = __builtin_amdgcn_s_memtime() - clk0, r1 = __builtin_amdgcn_s_memrealtime() - rt0;
+            if (lane == 0) { g.clk[0] = c1; g.clk[1] = r1; }
+        }
+    }
     if constexpr (OP == OP_LAUUM && TM == 128) {
         // z = A^-1 b rides on the tiles of A^-1 while they are in registers (a pass over A^-1 of its own costs 0.1 ms at
         // the headline size): tile (r, c) contributes p1 = V_rc b_c to z_r and, off the diagonal, p2 = V_rc^T b_r to z_c.
@@ -2414,6 +2429,7 @@ int do_lauum(hipStream_t st, const Ws& w, const lcgp_sched& sc, bool* z_partials
     // workspace may then be stale and the partials are never read): one launch shape to measure and to maintain
     g.bvec = w.base + w.off_b;
     g.part = (double*)(w.base + w.off_part);
+    g.clk = (unsigned long long*)(w.base + w.off_clock);
     if (z_partials) *z_partials = true;
     return launch_gemm<T, OP_LAUUM, 128>(st, g, nb2 * (nb2 + 1) / 2, w.q);
 }
@@ -2714,6 +2730,18 @@ int lcgp_lauum(void* stream, int dtype, int n, int d, int p, int q_local, void* 
     if ((rc = resolve_sched(sched, sc))) return rc;
     Ws w = carve(dtype, n, d, p, q_local, workspace);
     return dtype == LCGP_F64 ? do_lauum<double>((hipStream_t)stream, w, sc) : do_lauum<float>((hipStream_t)stream, w, sc);
+}
+
+int lcgp_lauum_clock(void* stream, int dtype, int n, int d, int p, int q_local, const void* workspace,
+                     unsigned long long* out) {
+    int rc = check_common(dtype, n, d, p, q_local);
+    if (rc) return rc;
+    if (!workspace || !out) return bad("NULL pointer");
+    Ws w = carve(dtype, n, d, p, q_local, (void*)workspace);
+    hipError_t e = hipMemcpyAsync(out, w.base + w.off_clock, 2 * sizeof(unsigned long long), hipMemcpyDeviceToDevice,
+                                  (hipStream_t)stream);
+    if (e != hipSuccess) return fail("hipMemcpyAsync", e);
+    return 0;
 }
 
 int lcgp_fetch_matrix(void* stream, int dtype, int n, int d, int p, int q_local, const void* workspace, int which, int k,

@@ -216,3 +216,22 @@ def test_predict_chunks_agree_with_one_call():
             np.testing.assert_allclose(a.numpy(), b, rtol=1e-12, atol=1e-13)
     finally:
         eng_mod.PREDICT_CHUNK = old
+
+
+def test_the_inverse_launch_reports_the_clock_it_ran_at():
+    """lcgp_lauum_clock: shader-clock cycles and 10 ns ticks of the longest K loop of the last A^-1 = W^T W launch (the same
+    launch lcgp_nll_grad enqueues at this size): a plausible MI355X clock, measured in the un-profiled path."""
+    import ctypes as C
+    import torch
+    from lcgp_amd import _hip, synth
+    x, y = synth.make_full(77, 2048, 3, 6, 4)
+    m = LCGP(y=y, x=x, q=4)
+    m.loss()
+    eng = m._engine
+    clk = torch.zeros(2, dtype=torch.int64, device=eng.device)
+    _hip.check(eng.lib.lcgp_lauum_clock(eng._stream(), eng.dtype, eng.n, eng.d, eng.p, eng.q_local, eng._p(eng.workspace),
+                                        C.c_void_p(clk.data_ptr())), 'lcgp_lauum_clock')
+    cyc, ticks = (int(v) for v in clk.cpu())
+    assert ticks > 0 and cyc > 0
+    mhz = 100.0 * cyc / ticks
+    assert 500.0 < mhz < 3000.0, mhz

@@ -73,6 +73,12 @@ def main():
         'write_kb_per_launch': w_kb,
         'algorithmic_bytes_per_launch': 1073741824.0,
     }
+    try:
+        mf = per_kernel(os.path.join(src, 'pmc_mfma'), 'SQ_VALU_MFMA_BUSY_CYCLES')
+        ga = per_kernel(os.path.join(src, 'pmc_mfma'), 'GRBM_GUI_ACTIVE')
+        traffic['tile_gemm_lauum_mfma_busy'] = mf[lau][1] / (1024.0 * ga[lau][1] / 8.0)
+    except Exception as exc:             # (no MFMA pass in this run)
+        print('no MFMA-busy figure:', exc)
     json.dump(traffic, open(os.path.join(dst, 'traffic.json'), 'w'), indent=1)
     # HBM traffic and MFMA busy per kernel and evaluation (3 evaluations per pass)
     lines = ['# HBM-side traffic per evaluation and kernel (n=4096 q=8 fp64), from %s_pmc_fetch_size.txt / %s_pmc_write_size.txt' % (pre, pre),
