@@ -228,6 +228,10 @@ def test_the_inverse_launch_reports_the_clock_it_ran_at():
     m = LCGP(y=y, x=x, q=4)
     m.loss()
     eng = m._engine
+    sc = _hip.default_sched()
+    sc.lauum_small_tiles = 0            # the 128x128-tile launch (the default at the headline size), which carries the stamps
+    _hip.check(eng.lib.lcgp_lauum(eng._stream(), eng.dtype, eng.n, eng.d, eng.p, eng.q_local, eng._p(eng.workspace), C.byref(sc)),
+               'lcgp_lauum')
     clk = torch.zeros(2, dtype=torch.int64, device=eng.device)
     _hip.check(eng.lib.lcgp_lauum_clock(eng._stream(), eng.dtype, eng.n, eng.d, eng.p, eng.q_local, eng._p(eng.workspace),
                                         C.c_void_p(clk.data_ptr())), 'lcgp_lauum_clock')
