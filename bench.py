@@ -422,11 +422,14 @@ def main():
         # ~1 KB per evaluation is the only thing a real job adds).  A PROJECTION, printed so that the first measured
         # SCALE record can be read against it -- never a measured multi-GPU number.
         q_full = int(synth.CONFIGS[args.config]['q'])
-        if q_full % args.q == 0:
-            g = q_full // args.q
-            out['projected_from_q_local'] = dict(q_local=args.q, n_gpus=g, ms_per_step=out['ms_per_step'],
-                                                 evals_per_s=1e3 / out['ms_per_step'],
-                                                 note='projection from a one-GPU run of one rank\'s share; not a measured %d-GPU number' % g)
+        # every GPU count whose SLOWEST rank holds this many components (k -> rank k mod G: ceil(q / G) of them): with q = 6 on
+        # 4 GPUs the shares are 2 / 2 / 1 / 1 and the step is the 2-component share's
+        gs = [g for g in range(1, q_full + 1) if -(-q_full // g) == args.q]
+        if gs:
+            out['projected_from_q_local'] = dict(q_local=args.q, n_gpus=gs[0], n_gpus_with_this_slowest_share=gs,
+                                                 ms_per_step=out['ms_per_step'], evals_per_s=1e3 / out['ms_per_step'],
+                                                 note='projection from a one-GPU run of the slowest rank\'s share; not a measured '
+                                                      'multi-GPU number')
     if rank == 0:
         print(json.dumps(out))
     if world > 1:

@@ -39,7 +39,8 @@ def main():
     dst = os.path.join(ROOT, 'profiles')
     for a, b in (('bench.json', 'bench.json'), ('bench_cfg2.json', 'bench_cfg2.json'), ('bench_cfg4.json', 'bench_cfg4.json'),
                  ('bench_cfg5.json', 'bench_cfg5.json'), ('bench_q4.json', 'bench_q4.json'), ('bench_q2.json', 'bench_q2.json'),
-                 ('bench_q1.json', 'bench_q1.json'), ('bench_gloo2.json', 'bench_gloo2_one_gpu.json'),
+                 ('bench_q1.json', 'bench_q1.json'), ('bench_cfg5_q2.json', 'bench_cfg5_q2.json'), ('bench_cfg5_q1.json', 'bench_cfg5_q1.json'),
+                 ('bench_gloo2.json', 'bench_gloo2_one_gpu.json'),
                  ('host_overhead.txt', 'host_overhead.txt'), ('timeline_q1_progressive.txt', 'timeline_q1_progressive.txt'),
                  ('timeline_q1_classic.txt', 'timeline_q1_classic.txt'), ('fit_wallclock.txt', 'fit_wallclock.txt'),
                  ('timeline_q8.txt', 'timeline_q8.txt')):

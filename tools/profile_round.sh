@@ -19,6 +19,8 @@ step "bench, other configurations"
 for c in 2 4 5; do python3 $ROOT/bench.py --config $c --steps 6 --warmup 2 > $OUT/bench_cfg$c.json 2> $OUT/bench_cfg$c.err || exit 1; done
 step "bench, one rank's share of the headline configuration (q_local = 4, 2, 1)"
 for q in 4 2 1; do python3 $ROOT/bench.py --q $q --steps 12 --warmup 3 --no-cpu-baseline > $OUT/bench_q$q.json 2> $OUT/bench_q$q.err || exit 1; done
+step "bench, the slowest rank's share of configs[4] on 4 GPUs (q = 6 -> 2 / 2 / 1 / 1) and the 1-component share"
+for q in 2 1; do python3 $ROOT/bench.py --config 5 --q $q --steps 12 --warmup 3 --no-cpu-baseline > $OUT/bench_cfg5_q$q.json 2> $OUT/bench_cfg5_q$q.err || exit 1; done
 step "host overhead (caller-owned plan vs plan per call; q = 8 and one rank's share)"
 python3 $ROOT/tools/host_overhead.py 3 > $OUT/host_overhead.txt 2>&1 || exit 1
 python3 $ROOT/tools/host_overhead.py 3 1 >> $OUT/host_overhead.txt 2>&1 || exit 1
