@@ -14,6 +14,6 @@ for v in names[1:]:
     a = np.load('gpurun_out/%s_eval_%s.npy' % (tag, v))
     print(v, 'vs', names[0], 'bitwise equal:', bool(np.array_equal(a, ref)), 'max rel diff %.3e' % float(np.max(np.abs(a - ref) / (np.abs(ref) + 1e-300))))
 PY
-for q in 8 1; do
+for q in ${ABQ:-8 1}; do
   bash tools/ab_builds.sh "--q $q --reps 3 --steps 8" "$@" 2>&1 | tee gpurun_out/${TAG}_ab_q$q.txt
 done
