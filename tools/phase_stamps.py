@@ -70,6 +70,7 @@ for _kb in range(4):
 
 def build():
     s = open(SRC).read().replace('#include "../../include/lcgp_hip.h"', '#include "%s"' % os.path.join(ROOT, 'include', 'lcgp_hip.h'))
+    s = s.replace('#include "fill_sched.h"', '#include "%s"' % os.path.join(ROOT, 'lcgp_amd', 'csrc', 'fill_sched.h'))
     for old, new in PATCHES:
         assert s.count(old) == 1, 'anchor drifted: %r' % old[:60]
         s = s.replace(old, new)
