@@ -239,3 +239,32 @@ def test_the_inverse_launch_reports_the_clock_it_ran_at():
     assert ticks > 0 and cyc > 0
     mhz = 100.0 * cyc / ticks
     assert 500.0 < mhz < 3000.0, mhz
+
+
+def test_bench_line_keeps_its_contract():
+    """`python bench.py` prints ONE JSON line with the fields the driver reads (metric / value / unit / n_gpus / steps / warmup /
+    ms_per_step / higher_is_better / scaling / vs_baseline / dtype / data / config.workload) plus the `roofline` block of the
+    dominant kernel, measured live (HIP events, in-kernel clock).  Run as the driver runs it, in a process of its own."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '1', '--steps', '3', '--warmup', '1',
+                          '--no-cpu-baseline', '--no-fit', '--predict', '0', '--blocks', '1'],
+                         capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d['metric'] == 'NLL+grad evals/sec' and d['unit'] == 'evals/s' and d['higher_is_better'] is True
+    assert d['n_gpus'] == 1 and d['steps'] == 3 and d['warmup'] == 1 and d['dtype'] == 'f64' and d['data'] == 'synthetic'
+    assert d['vs_baseline'] is None and d['scaling'] in ('strong', 'weak') and 'n=4096' in d['config']['workload']
+    assert abs(d['value'] - 1e3 / d['ms_per_step']) < 1e-6 * d['value'] and 20.0 < d['value'] < 500.0
+    r = d['roofline']
+    assert r['bound'] == 'mfma' and r['unit'] == 'TFLOP/s' and r['peak'] == 78.6
+    assert abs(r['frac'] - r['achieved'] / r['peak']) < 1e-12 and 0.3 < r['frac'] < 1.0
+    assert abs(r['achieved'] - r['flops_per_launch'] / (r['launch_ms'] * 1e-3) / 1e12) < 1e-9 * r['achieved']
+    assert 1000.0 < r['clock_mhz'] < 2600.0 and r['clock_window_us'] > 100.0
+    assert r['traffic'] is None or r['traffic'] > 1e9
+    assert set(d['roofline_stages']) == {'potrf', 'trtri', 'lauum'}
