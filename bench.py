@@ -59,6 +59,8 @@ def stage_times(m, reps=3):
     ws = C.c_void_p(eng.workspace.data_ptr())
     names = ['build', 'potrf', 'trtri', 'lauum']
     acc = {k: [] for k in names}
+    clk = torch.zeros(2, dtype=torch.int64, device=eng.device)
+    _hip.check(lib.lcgp_lauum_clock(sp, *args, ws, C.c_void_p(clk.data_ptr())), 'lauum_clock')     # (read and clear: drops stale words)
     for _ in range(reps):
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(5)]
         ev[0].record(st)
@@ -77,7 +79,6 @@ def stage_times(m, reps=3):
     out = {k: float(np.median(v)) for k, v in acc.items()}
     # the clock the chip held during the last A^-1 launch above (un-profiled): its first workgroup stamps its K loop with the
     # shader-clock counter and the 100 MHz real-time counter (lcgp_lauum_clock)
-    clk = torch.zeros(2, dtype=torch.int64, device=eng.device)
     _hip.check(lib.lcgp_lauum_clock(sp, *args, ws, C.c_void_p(clk.data_ptr())), 'lauum_clock')
     cyc, ticks = (int(v) for v in clk.cpu())
     return out, dict(clock_mhz=100.0 * cyc / ticks if ticks > 0 else None, clock_window_us=ticks / 100.0)

@@ -2741,6 +2741,10 @@ int lcgp_lauum_clock(void* stream, int dtype, int n, int d, int p, int q_local, 
     hipError_t e = hipMemcpyAsync(out, w.base + w.off_clock, 2 * sizeof(unsigned long long), hipMemcpyDeviceToDevice,
                                   (hipStream_t)stream);
     if (e != hipSuccess) return fail("hipMemcpyAsync", e);
+    // read and clear: a second read without a stamped launch in between returns zeros (the 64x64-tile form of the launch,
+    // which small problems and single components use, does not stamp), and so does a read after one call on a fresh workspace
+    e = hipMemsetAsync(w.base + w.off_clock, 0, 2 * sizeof(unsigned long long), (hipStream_t)stream);
+    if (e != hipSuccess) return fail("hipMemsetAsync", e);
     return 0;
 }
 

@@ -239,6 +239,10 @@ def test_the_inverse_launch_reports_the_clock_it_ran_at():
     assert ticks > 0 and cyc > 0
     mhz = 100.0 * cyc / ticks
     assert 500.0 < mhz < 3000.0, mhz
+    # read-and-clear: without another stamped launch the words are zero
+    _hip.check(eng.lib.lcgp_lauum_clock(eng._stream(), eng.dtype, eng.n, eng.d, eng.p, eng.q_local, eng._p(eng.workspace),
+                                        C.c_void_p(clk.data_ptr())), 'lcgp_lauum_clock')
+    assert [int(v) for v in clk.cpu()] == [0, 0]
 
 
 def test_bench_line_keeps_its_contract():
