@@ -56,7 +56,9 @@ class HotPathEngine:
             _hip.check(self.lib.lcgp_workspace_bytes(self.dtype, self.n, self.d, self.p, self.q_local, C.byref(nbytes)),
                        "lcgp_workspace_bytes")
             self.workspace_bytes = int(nbytes.value)
-            self.workspace = torch.empty(self.workspace_bytes, dtype=torch.uint8, device=self.device)
+            # zero-filled, i.e. touched once here: the first evaluation of a fresh engine otherwise pays 30-70 ms of first-touch
+            # page mapping for its 3 x q_local matrices inside the optimiser's first step (and the clock words start at zero)
+            self.workspace = torch.zeros(self.workspace_bytes, dtype=torch.uint8, device=self.device)
             self.tw = self.lib.lcgp_theta_width(self.d, self.p)
             self.ow = self.lib.lcgp_out_width(self.d, self.p)
             self.pw = self.lib.lcgp_partial_width(self.d, self.p, self.q_total)
