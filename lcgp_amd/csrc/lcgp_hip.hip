@@ -742,6 +742,87 @@ __device__ __forceinline__ void store_stage(T* __restrict__ S, const T (&reg)[TM
     }
 }
 
+// ---- hand-counted operand prefetch (the triangular products of the inverse) ----
+// hipcc's wait-count pass puts `s_waitcnt vmcnt(3..0)` in front of the first LDS store of every double stage of the register
+// prefetch loop below, although the set being stored is the OLDER of two outstanding ones (it needs vmcnt(4..7)): the stage
+// fetched one compute stage ago is waited for as well and the second stage of prefetch covers no latency (the pass is
+// conservative at the loop header whether or not the loads sit under a condition; the same loop with unconditional loads
+// compiles to the same waits).  So the loads of that loop are issued through inline asm, which the pass does not track, and
+// the waits are written out: vector-memory operations retire in order, so with PF sets of NL loads outstanding the oldest
+// set is complete at vmcnt((PF - 1) NL).  The asm that waits takes the set's registers as read-write operands, so every
+// use of them is ordered behind it.  Compiler-generated waits stay correct beside this (they can only wait for more).
+template <typename T> struct Piece;
+template <> struct Piece<double> { typedef double v __attribute__((ext_vector_type(2))); };
+template <> struct Piece<float> { typedef float v __attribute__((ext_vector_type(4))); };
+
+// one 16-byte piece: address = wave-uniform base (SGPR pair) + per-lane byte offset (one VGPR, loop-invariant) + immediate.
+// The scalar base keeps the whole address arithmetic of a stage on the scalar unit: the fp64 128-tile kernels sit at the
+// 128-register limit of four waves per SIMD, and 64-bit per-lane pointers spilled there (a spill reload inside the K loop
+// is a scratch load, i.e. a vmcnt(0) wait for every prefetched stage).
+template <int IMM, typename P>
+__device__ __forceinline__ void gload_piece(P& dst, unsigned voff, const void* sbase) {
+    asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=v"(dst) : "v"(voff), "s"(sbase), "n"(IMM) : "memory");
+}
+
+template <int N, typename P>
+__device__ __forceinline__ void vm_wait_set(P (&a)[1], P (&b)[1]) {
+    asm volatile("s_waitcnt vmcnt(%2)" : "+v"(a[0]), "+v"(b[0]) : "n"(N) : "memory");
+}
+template <int N, typename P>
+__device__ __forceinline__ void vm_wait_set(P (&a)[2], P (&b)[2]) {
+    asm volatile("s_waitcnt vmcnt(%4)" : "+v"(a[0]), "+v"(a[1]), "+v"(b[0]), "+v"(b[1]) : "n"(N) : "memory");
+}
+
+// the same stage image as load_stage / store_stage, the registers as 16-byte pieces (NPC = EPT sizeof(T) / 16 per lane)
+// byte offset of this lane's first piece within a stage of an operand tile
+template <typename T, int L, int TM, int NT>
+__device__ __forceinline__ unsigned stage_lane_offset(int ld, int tid) {
+    constexpr int EPT = TM * KT / NT;
+    constexpr int PE = 16 / (int)sizeof(T);
+    if (L == MK) {
+        constexpr int TPR = KT / EPT;
+        const int m = tid / TPR, kk = (tid % TPR) * EPT;
+        return (unsigned)((m * ld + kk) * (int)sizeof(T));
+    } else {
+        constexpr int TPK = TM / EPT;
+        const int kq = tid / TPK, j = tid % TPK;
+        return (unsigned)((kq * ld + j * PE) * (int)sizeof(T));
+    }
+}
+
+template <typename T, int L, int TM, int NT, int PC = 0>
+__device__ __forceinline__ void load_stage_p(const T* __restrict__ P /*wave-uniform*/, int ld, int ks,
+                                             typename Piece<T>::v (&reg)[TM * KT / NT * (int)sizeof(T) / 16], unsigned voff) {
+    constexpr int EPT = TM * KT / NT;
+    constexpr int PE = 16 / (int)sizeof(T), NP = EPT / PE;
+    const T* base = L == MK ? P + ks : P + (size_t)ks * ld;
+    constexpr int STEP = (L == MK ? PE : TM / NP) * (int)sizeof(T);      // bytes between the pieces of a lane
+    if constexpr (PC < NP) {
+        gload_piece<PC * STEP>(reg[PC], voff, base);
+        load_stage_p<T, L, TM, NT, PC + 1>(P, ld, ks, reg, voff);
+    }
+}
+
+template <typename T, int L, int TM, int NT>
+__device__ __forceinline__ void store_stage_p(T* __restrict__ S, const typename Piece<T>::v (&reg)[TM * KT / NT * (int)sizeof(T) / 16],
+                                              int tid) {
+    constexpr int EPT = TM * KT / NT;
+    constexpr int LD = TM + 16;
+    constexpr int PE = 16 / (int)sizeof(T), NP = EPT / PE;
+    if (L == MK) {
+        constexpr int TPR = KT / EPT;
+        const int m = tid / TPR, kk = (tid % TPR) * EPT;
+#pragma unroll
+        for (int e = 0; e < EPT; ++e) S[(kk + e) * LD + (m ^ lds_swz<T>(kk + e))] = reg[e / PE][e % PE];
+    } else {
+        constexpr int TPK = TM / EPT;
+        const int kq = tid / TPK, j = tid % TPK;
+#pragma unroll
+        for (int pc = 0; pc < NP; ++pc)
+            *(typename Piece<T>::v*)&S[kq * LD + ((j * PE + pc * (TM / NP)) ^ lds_swz<T>(kq))] = reg[pc];
+    }
+}
+
 // Workgroups are dealt round-robin over the 8 XCDs (each with its own L2).  Remap the linear tile id so that
 // every XCD works on one contiguous run of tiles (neighbouring tiles share operand panels): bijective for any
 // grid size (speed only, never correctness).
@@ -953,6 +1034,64 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, const int lin /*blo
         // MFMA work per workgroup: enough to cover an L2/HBM round trip with two workgroups per CU); deeper would spill.
         constexpr bool F64 = sizeof(T) == 8;
         constexpr int PF = OP == OP_SYRK ? (F64 ? 1 : 2) : (TM == 64 ? (F64 ? 2 : 4) : 2);
+        constexpr int NPC = EPT * (int)sizeof(T) / 16;      // 16-byte pieces per lane, operand and stage
+#ifndef LCGP_NO_COUNTED_PREFETCH
+        constexpr bool COUNTED = !PRELOAD_C && PF == 2 && (NPC == 1 || NPC == 2);
+#else
+        constexpr bool COUNTED = false;
+#endif
+        if constexpr (COUNTED) {
+            // the hand-counted form of the loop below (see gload_piece): same stage images, same order of arithmetic
+            typedef typename Piece<T>::v pc_t;
+            constexpr int NL = 2 * NPC;                     // loads per register set
+            pc_t qa[PF][NPC], qb[PF][NPC];
+            const unsigned voffA = stage_lane_offset<T, LA, TM, NT>(g.ldA, tid), voffB = stage_lane_offset<T, LB, TM, NT>(g.ldB, tid);
+#pragma unroll
+            for (int h = 0; h < PF; ++h) {
+                if (h < nst) {
+                    const int kt = h / SPT, ks = (h % SPT) * KT;
+                    load_stage_p<T, LA, TM, NT>(A0 + (ptrdiff_t)kt * dA, g.ldA, ks, qa[h], voffA);
+                    load_stage_p<T, LB, TM, NT>(B0 + (ptrdiff_t)kt * dB, g.ldB, ks, qb[h], voffB);
+                }
+            }
+            int s = 0;
+            // main part: every stage of a pass exists and has a stage PF ahead to fetch: PF sets are outstanding whenever
+            // one is stored, the oldest of them is complete at vmcnt((PF - 1) NL)
+            for (; s + 2 * PF <= nst; s += PF) {
+#pragma unroll
+                for (int h = 0; h < PF; ++h) {
+                    const int buf = h & 1;
+                    vm_wait_set<(PF - 1) * NL>(qa[h], qb[h]);
+                    store_stage_p<T, LA, TM, NT>(As + buf * KT * LD, qa[h], tid);
+                    store_stage_p<T, LB, TM, NT>(Bs + buf * KT * LD, qb[h], tid);
+                    __syncthreads();
+                    const int kt = (s + h + PF) / SPT, ks = ((s + h + PF) % SPT) * KT;
+                    load_stage_p<T, LA, TM, NT>(A0 + (ptrdiff_t)kt * dA, g.ldA, ks, qa[h], voffA);
+                    load_stage_p<T, LB, TM, NT>(B0 + (ptrdiff_t)kt * dB, g.ldB, ks, qb[h], voffB);
+                    if (wave_live(s + h)) compute_stage(buf);
+                }
+            }
+            // the last (up to 2 PF - 1) stages: fewer sets in flight, wait for all of them
+            for (; s < nst; s += PF) {
+#pragma unroll
+                for (int h = 0; h < PF; ++h) {
+                    if (s + h < nst) {
+                        const int buf = h & 1;
+                        vm_wait_set<0>(qa[h], qb[h]);
+                        store_stage_p<T, LA, TM, NT>(As + buf * KT * LD, qa[h], tid);
+                        store_stage_p<T, LB, TM, NT>(Bs + buf * KT * LD, qb[h], tid);
+                        __syncthreads();
+                        if (s + h + PF < nst) {
+                            const int kt = (s + h + PF) / SPT, ks = ((s + h + PF) % SPT) * KT;
+                            load_stage_p<T, LA, TM, NT>(A0 + (ptrdiff_t)kt * dA, g.ldA, ks, qa[h], voffA);
+                            load_stage_p<T, LB, TM, NT>(B0 + (ptrdiff_t)kt * dB, g.ldB, ks, qb[h], voffB);
+                        }
+                        if (wave_live(s + h)) compute_stage(buf);
+                    }
+                }
+            }
+            // (nothing the asm loaded is outstanding here: the last stored set was waited for with vmcnt(0))
+        } else {
         T ra[PF][EPT], rb[PF][EPT];
 #pragma unroll
         for (int h = 0; h < PF; ++h) {
@@ -978,6 +1117,7 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, const int lin /*blo
                     if (wave_live(s + h)) compute_stage(buf);
                 }
             }
+        }
         }
     }
 #pragma unroll

@@ -24,6 +24,7 @@ def main():
     ap.add_argument('--config', type=int, default=3, help='BASELINE.json configuration (3 = headline fp64, 4 = fp32 n=16384)')
     ap.add_argument('--reps', type=int, default=4)
     ap.add_argument('--steps', type=int, default=6)
+    ap.add_argument('--stages', action='store_true', help='also print the HIP-event times of the stages (bench.py: stage_times)')
     ap.add_argument('settings', nargs='+')
     a = ap.parse_args()
     x, y, cfg = synth.make_config(a.config)
@@ -67,6 +68,12 @@ def main():
             torch.cuda.synchronize()
             res[name].append((time.perf_counter() - t0) / a.steps * 1e3)
     apply(())
+    if a.stages:
+        sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
+        import bench
+        m._engine = eng
+        st, clk = bench.stage_times(m, reps=5)
+        print('   stages (ms): ' + '  '.join('%s %.3f' % (k, v) for k, v in st.items()) + '   clock %s MHz' % (clk['clock_mhz'] and round(clk['clock_mhz'])))
     for name, _ in names:
         v = np.array(res[name])
         print(f"{name:28s} min {v.min():8.3f} ms   mean {v.mean():8.3f} ms   ({a.reps} x {a.steps} evaluations, q_local={a.q}, n={a.n})")

@@ -15,5 +15,5 @@ for v in names[1:]:
     print(v, 'vs', names[0], 'bitwise equal:', bool(np.array_equal(a, ref)), 'max rel diff %.3e' % float(np.max(np.abs(a - ref) / (np.abs(ref) + 1e-300))))
 PY
 for q in ${ABQ:-8 1}; do
-  bash tools/ab_builds.sh "--q $q --reps 3 --steps 8" "$@" 2>&1 | tee gpurun_out/${TAG}_ab_q$q.txt
+  bash tools/ab_builds.sh "--q $q --reps 3 --steps 8 ${ABEXTRA:-}" "$@" 2>&1 | tee gpurun_out/${TAG}_ab_q$q.txt
 done
