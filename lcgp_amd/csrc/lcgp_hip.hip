@@ -1046,13 +1046,16 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, const int lin /*blo
             constexpr int NL = 2 * NPC;                     // loads per register set
             pc_t qa[PF][NPC], qb[PF][NPC];
             const unsigned voffA = stage_lane_offset<T, LA, TM, NT>(g.ldA, tid), voffB = stage_lane_offset<T, LB, TM, NT>(g.ldB, tid);
+            // NO control flow between an asm load and the wait that covers it: at a join the compiler may move a value to
+            // another register, and a move placed behind the asm copies the register before the data has arrived.  The number
+            // of stages is a positive multiple of SPT >= 4, so the first PF stages exist and the loop ends with exactly PF
+            // stages that have nothing left to fetch.
+            static_assert(SPT % PF == 0 && SPT >= 2 * PF, "stage count of a k tile");
 #pragma unroll
             for (int h = 0; h < PF; ++h) {
-                if (h < nst) {
-                    const int kt = h / SPT, ks = (h % SPT) * KT;
-                    load_stage_p<T, LA, TM, NT>(A0 + (ptrdiff_t)kt * dA, g.ldA, ks, qa[h], voffA);
-                    load_stage_p<T, LB, TM, NT>(B0 + (ptrdiff_t)kt * dB, g.ldB, ks, qb[h], voffB);
-                }
+                const int kt = h / SPT, ks = (h % SPT) * KT;
+                load_stage_p<T, LA, TM, NT>(A0 + (ptrdiff_t)kt * dA, g.ldA, ks, qa[h], voffA);
+                load_stage_p<T, LB, TM, NT>(B0 + (ptrdiff_t)kt * dB, g.ldB, ks, qb[h], voffB);
             }
             int s = 0;
             // main part: every stage of a pass exists and has a stage PF ahead to fetch: PF sets are outstanding whenever
@@ -1061,34 +1064,35 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, const int lin /*blo
 #pragma unroll
                 for (int h = 0; h < PF; ++h) {
                     const int buf = h & 1;
-                    vm_wait_set<(PF - 1) * NL>(qa[h], qb[h]);
-                    store_stage_p<T, LA, TM, NT>(As + buf * KT * LD, qa[h], tid);
-                    store_stage_p<T, LB, TM, NT>(Bs + buf * KT * LD, qb[h], tid);
-                    __syncthreads();
-                    const int kt = (s + h + PF) / SPT, ks = ((s + h + PF) % SPT) * KT;
-                    load_stage_p<T, LA, TM, NT>(A0 + (ptrdiff_t)kt * dA, g.ldA, ks, qa[h], voffA);
-                    load_stage_p<T, LB, TM, NT>(B0 + (ptrdiff_t)kt * dB, g.ldB, ks, qb[h], voffB);
-                    if (wave_live(s + h)) compute_stage(buf);
-                }
-            }
-            // the last (up to 2 PF - 1) stages: fewer sets in flight, wait for all of them
-            for (; s < nst; s += PF) {
-#pragma unroll
-                for (int h = 0; h < PF; ++h) {
-                    if (s + h < nst) {
-                        const int buf = h & 1;
-                        vm_wait_set<0>(qa[h], qb[h]);
+#ifndef LCGP_EXP
+#define LCGP_EXP 0
+#endif
+                    // (LCGP_EXP: destructive timing experiments, never in a product build -- 1: no operand loads, 2: no LDS
+                    // stores / barrier, 8: no MFMA stage; results are garbage)
+                    if constexpr (!(LCGP_EXP & 1)) vm_wait_set<(PF - 1) * NL>(qa[h], qb[h]);
+                    if constexpr (!(LCGP_EXP & 2)) {
                         store_stage_p<T, LA, TM, NT>(As + buf * KT * LD, qa[h], tid);
                         store_stage_p<T, LB, TM, NT>(Bs + buf * KT * LD, qb[h], tid);
                         __syncthreads();
-                        if (s + h + PF < nst) {
-                            const int kt = (s + h + PF) / SPT, ks = ((s + h + PF) % SPT) * KT;
-                            load_stage_p<T, LA, TM, NT>(A0 + (ptrdiff_t)kt * dA, g.ldA, ks, qa[h], voffA);
-                            load_stage_p<T, LB, TM, NT>(B0 + (ptrdiff_t)kt * dB, g.ldB, ks, qb[h], voffB);
-                        }
-                        if (wave_live(s + h)) compute_stage(buf);
                     }
+                    const int kt = (s + h + PF) / SPT, ks = ((s + h + PF) % SPT) * KT;
+                    if constexpr (!(LCGP_EXP & 1)) {
+                        load_stage_p<T, LA, TM, NT>(A0 + (ptrdiff_t)kt * dA, g.ldA, ks, qa[h], voffA);
+                        load_stage_p<T, LB, TM, NT>(B0 + (ptrdiff_t)kt * dB, g.ldB, ks, qb[h], voffB);
+                    }
+                    if constexpr (!(LCGP_EXP & 8))
+                    if (wave_live(s + h)) compute_stage(buf);
                 }
+            }
+            // the last PF stages (s = nst - PF here): nothing left to fetch, the sets in flight are waited for together
+#pragma unroll
+            for (int h = 0; h < PF; ++h) {
+                const int buf = h & 1;
+                vm_wait_set<0>(qa[h], qb[h]);
+                store_stage_p<T, LA, TM, NT>(As + buf * KT * LD, qa[h], tid);
+                store_stage_p<T, LB, TM, NT>(Bs + buf * KT * LD, qb[h], tid);
+                __syncthreads();
+                if (wave_live(s + h)) compute_stage(buf);
             }
             // (nothing the asm loaded is outstanding here: the last stored set was waited for with vmcnt(0))
         } else {
