@@ -100,6 +100,8 @@ template <> struct Mfma<double> {
         return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
     }
     static __device__ __forceinline__ int row(int lane, int reg) { return (lane >> 4) + 4 * reg; }
+    static __device__ __forceinline__ int lane_row(int lane) { return lane >> 4; }      // row = lane_row + reg_row
+    static __device__ __forceinline__ constexpr int reg_row(int reg) { return 4 * reg; }
 };
 template <> struct Mfma<float> {
     typedef f4 acc_t;
@@ -107,6 +109,33 @@ template <> struct Mfma<float> {
         return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
     }
     static __device__ __forceinline__ int row(int lane, int reg) { return (lane >> 4) * 4 + reg; }
+    static __device__ __forceinline__ int lane_row(int lane) { return (lane >> 4) * 4; }
+    static __device__ __forceinline__ constexpr int reg_row(int reg) { return reg; }
+};
+
+// Buffer addressing of a tile: descriptor (base pointer, in scalar registers) + scalar byte offset + one per-lane byte
+// offset register + immediate.  An accumulator tile addressed through 64-bit per-lane pointers costs two registers per
+// distinct row of the MFMA lane map (16 of the 128 a wave of the fp64 128-tile kernels may use), held across the K loop.
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t tile_rsrc(const void* base) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, 0x7fffffff, 0x00020000);
+}
+template <typename T> struct BufIo;
+template <> struct BufIo<double> {
+    typedef unsigned u2 __attribute__((ext_vector_type(2)));
+    static __device__ __forceinline__ double load(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+        return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0));
+    }
+    static __device__ __forceinline__ void store(double v, __amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u2, v), r, voff, soff, 0);
+    }
+};
+template <> struct BufIo<float> {
+    static __device__ __forceinline__ float load(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+        return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
+    }
+    static __device__ __forceinline__ void store(float v, __amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, voff, soff, 0);
+    }
 };
 
 // Thread index of a tile body.  Opaque to the optimiser on purpose: where bodies sit in a loop (the chain workgroup of
@@ -655,6 +684,9 @@ __global__ __launch_bounds__(256, 2) void leaf_kernel(T* __restrict__ M, T* __re
 //   MK : element (m, k) at P[m * ld + k]      KM : element (m, k) at P[k * ld + m]
 // and staged in LDS as [k][m] (KT = 16 k rows per stage, double buffered through registers).
 // ---------------------------------------------------------------------------------------------------
+#ifndef LCGP_EXP
+#define LCGP_EXP 0      // destructive timing experiments (tools/build_variant.sh ... -DLCGP_EXP=n); 0 in every product build
+#endif
 enum GemmOp { OP_SYRK = 1, OP_TRTRI_T = 2, OP_TRTRI_W = 3, OP_LAUUM = 4, OP_PRED_U = 5 };
 enum Lay { MK = 0, KM = 1 };
 
@@ -790,6 +822,26 @@ __device__ __forceinline__ unsigned stage_lane_offset(int ld, int tid) {
     }
 }
 
+// load_stage with the address split into a wave-uniform base (scalar registers) and this lane's offset within a stage
+// (stage_lane_offset, bytes; loop-invariant): the compiler then uses the scalar-base form of global_load and no per-lane
+// 64-bit pointer lives across the K loop
+template <typename T, int L, int TM, int NT>
+__device__ __forceinline__ void load_stage_u(const T* __restrict__ P /*wave-uniform*/, int ld, int ks, T (&reg)[TM * KT / NT],
+                                             unsigned voff) {
+    constexpr int EPT = TM * KT / NT;
+    const T* src = (const T*)((const char*)(L == MK ? P + ks : P + (size_t)ks * ld) + voff);
+    if (L == MK) {
+#pragma unroll
+        for (int e = 0; e < EPT; ++e) reg[e] = src[e];
+    } else {
+        constexpr int PE = 16 / (int)sizeof(T), NP = EPT / PE;
+#pragma unroll
+        for (int pc = 0; pc < NP; ++pc)
+#pragma unroll
+            for (int e = 0; e < PE; ++e) reg[pc * PE + e] = src[pc * (TM / NP) + e];
+    }
+}
+
 template <typename T, int L, int TM, int NT, int PC = 0>
 __device__ __forceinline__ void load_stage_p(const T* __restrict__ P /*wave-uniform*/, int ld, int ks,
                                              typename Piece<T>::v (&reg)[TM * KT / NT * (int)sizeof(T) / 16], unsigned voff) {
@@ -821,6 +873,32 @@ __device__ __forceinline__ void store_stage_p(T* __restrict__ S, const typename 
         for (int pc = 0; pc < NP; ++pc)
             *(typename Piece<T>::v*)&S[kq * LD + ((j * PE + pc * (TM / NP)) ^ lds_swz<T>(kq))] = reg[pc];
     }
+}
+
+// ---- row image of a k-contiguous fp64 operand (gemm_body only) ----
+// A k-contiguous operand (MK: a lane holds 4 consecutive k of one row m) went into the [k][m] image through a TRANSPOSING
+// store: four ds_write_b64 per lane, operand and stage, behind the XOR that makes them conflict-free.  Kept as it lies in
+// memory instead -- S[m * LDK + k], LDK = KT + 2 doubles -- a lane stores its 32 bytes as two 16-byte pieces (half the LDS
+// store instructions, whose issue + wait + barrier in front of every stage cost the rank-256 update 18 % of its time:
+// profiles/r06_syrk_destructive.txt) and the TRANSPOSITION moves to the fragment read, where it is free: lane (i, kq) of an
+// MFMA operand reads S[(m0 + i) LDK + k0 + kq], and with 36 dwords per row the 16 rows of a 32-lane ds_read_b64 group start
+// on 16 different multiples of 4 banks (36 i mod 64), two banks each, the second k of the group two banks further: all 64
+// banks once.  One address register per operand (the swizzled [k][m] image needs one per k step).
+constexpr int LDK = KT + 2;
+template <int TM, int NT>
+__device__ __forceinline__ void store_stage_rows(double* __restrict__ S, const double (&reg)[TM * KT / NT], int tid) {
+    constexpr int EPT = TM * KT / NT, TPR = KT / EPT;
+    typedef double d2 __attribute__((ext_vector_type(2)));
+    const int m = tid / TPR, kk = (tid % TPR) * EPT;
+#pragma unroll
+    for (int pc = 0; pc < EPT / 2; ++pc) *(d2*)&S[m * LDK + kk + 2 * pc] = d2{reg[2 * pc], reg[2 * pc + 1]};
+}
+template <int TM, int NT>
+__device__ __forceinline__ void store_stage_rows_p(double* __restrict__ S, const Piece<double>::v (&reg)[TM * KT / NT / 2], int tid) {
+    constexpr int EPT = TM * KT / NT, TPR = KT / EPT;
+    const int m = tid / TPR, kk = (tid % TPR) * EPT;
+#pragma unroll
+    for (int pc = 0; pc < EPT / 2; ++pc) *(Piece<double>::v*)&S[m * LDK + kk + 2 * pc] = reg[pc];
 }
 
 // Workgroups are dealt round-robin over the 8 XCDs (each with its own L2).  Remap the linear tile id so that
@@ -942,6 +1020,13 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, const int lin /*blo
     const int wm0 = (wave >> 1) * WTM, wn0 = (wave & 1) * WTN;
     typedef typename Mfma<T>::acc_t acc_t;
     acc_t acc[MIM][MIN];
+    // address of accumulator element (i, j, e) in the C tile = wave-uniform part (scalar registers) + this lane's element offset
+    // (byte offsets: a 128-row tile of the largest matrix spans 128 x 16384 x 8 bytes)
+    const __amdgpu_buffer_rsrc_t crs = tile_rsrc(Ct);
+    const unsigned cvoff = (unsigned)(Mfma<T>::lane_row(lane) * g.ldC + (lane & 15)) * (unsigned)sizeof(T);
+    auto c_soff = [&](int i, int e) -> unsigned {
+        return (unsigned)((wm0 + i * 16 + Mfma<T>::reg_row(e)) * g.ldC + wn0) * (unsigned)sizeof(T);
+    };
     // C -= A B^T: the accumulators start from the C tile (its load overlaps the first operand loads) and the A
     // fragments are negated, so the epilogue is stores only
     constexpr bool PRELOAD_C = (OP == OP_SYRK);
@@ -951,10 +1036,8 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, const int lin /*blo
         for (int j = 0; j < MIN; ++j)
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                if constexpr (PRELOAD_C) {
-                    const int row = wm0 + i * 16 + Mfma<T>::row(lane, e);
-                    const int col = wn0 + j * 16 + (lane & 15);
-                    acc[i][j][e] = Ct[(size_t)row * g.ldC + col];
+                if constexpr (PRELOAD_C && !(LCGP_EXP & 16)) {
+                    acc[i][j][e] = BufIo<T>::load(crs, cvoff + j * 16 * (unsigned)sizeof(T), c_soff(i, e));
                 } else {
                     acc[i][j][e] = 0;
                 }
@@ -983,6 +1066,20 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, const int lin /*blo
     else if constexpr (OP == OP_TRTRI_W) dead_lo = tri_first + (wm0 + WTM) / KT;
     else if constexpr (OP == OP_PRED_U) dead_lo = tri_first + (wn0 + WTN) / KT;
     auto wave_live = [&](int sg) { return !HAS_TRI || sg < dead_lo || sg >= dead_hi; };
+#ifndef LCGP_NO_ROW_IMAGE
+    constexpr bool ROWS_A = LA == MK && sizeof(T) == 8, ROWS_B = LB == MK && sizeof(T) == 8;     // (store_stage_rows)
+#else
+    constexpr bool ROWS_A = false, ROWS_B = false;
+#endif
+    static_assert(TM * LDK <= KT * LD, "the row image fits the stage buffer");
+    auto put_a = [&](T* S, const T (&reg)[EPT]) {
+        if constexpr (ROWS_A) store_stage_rows<TM, NT>((double*)S, (const double (&)[EPT])reg, tid);
+        else store_stage<T, LA, TM, NT>(S, reg, tid);
+    };
+    auto put_b = [&](T* S, const T (&reg)[EPT]) {
+        if constexpr (ROWS_B) store_stage_rows<TM, NT>((double*)S, (const double (&)[EPT])reg, tid);
+        else store_stage<T, LB, TM, NT>(S, reg, tid);
+    };
     auto compute_stage = [&](int buf) {
         const T* as = As + buf * KT * LD;
         const T* bs = Bs + buf * KT * LD;
@@ -990,14 +1087,16 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, const int lin /*blo
 #pragma unroll
         for (int kk = 0; kk < KT / 4; ++kk) {
             const int krow = (kk * 4 + (lane >> 4)) * LD;
+            const int kcol = kk * 4 + (lane >> 4);
             T af[MIM], bf[MIN];
 #pragma unroll
             for (int i = 0; i < MIM; ++i) {
-                const T v = as[krow + wm0 + swz_col<T>(i * 16, l15, kk)];
+                const T v = ROWS_A ? as[(wm0 + i * 16 + l15) * LDK + kcol] : as[krow + wm0 + swz_col<T>(i * 16, l15, kk)];
                 af[i] = PRELOAD_C ? -v : v;
             }
 #pragma unroll
-            for (int j = 0; j < MIN; ++j) bf[j] = bs[krow + wn0 + swz_col<T>(j * 16, l15, kk)];
+            for (int j = 0; j < MIN; ++j)
+                bf[j] = ROWS_B ? bs[(wn0 + j * 16 + l15) * LDK + kcol] : bs[krow + wn0 + swz_col<T>(j * 16, l15, kk)];
 #pragma unroll
             for (int i = 0; i < MIM; ++i)
 #pragma unroll
@@ -1017,8 +1116,8 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, const int lin /*blo
             }
 #pragma unroll
             for (int s = 0; s < SPT; ++s) {
-                store_stage<T, LA, TM, NT>(As + (s & 1) * KT * LD, pa[s], tid);
-                store_stage<T, LB, TM, NT>(Bs + (s & 1) * KT * LD, pb[s], tid);
+                put_a(As + (s & 1) * KT * LD, pa[s]);
+                put_b(Bs + (s & 1) * KT * LD, pb[s]);
                 __syncthreads();
                 if (wave_live(s)) compute_stage(s & 1);
             }
@@ -1029,14 +1128,24 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, const int lin /*blo
         // register prefetch PF stages ahead (the loads of stage s+PF are issued while stage s is multiplied): with
         // few workgroups per CU one stage of MFMAs (~0.5 us) does not cover an HBM/L2 round trip; the 64-tile kernel,
         // whose launches are often a fraction of a round, looks a whole k tile ahead
-        // Depth by register budget (128 VGPRs per lane at the occupancy the launches need): the fp64 rank-k update
-        // holds its C tile in the accumulators from the start, so it looks ONE stage ahead (an fp64 stage is ~1.7 us of
-        // MFMA work per workgroup: enough to cover an L2/HBM round trip with two workgroups per CU); deeper would spill.
+        // Depth by register budget (128 VGPRs per lane at the occupancy the launches need): two stages everywhere since
+        // round 6 -- the fp64 rank-k update, which holds its C tile in the accumulators from the start, looked ONE stage
+        // ahead until the C tile moved to buffer addressing (one offset register instead of eight 64-bit row pointers) and
+        // the k-contiguous operands to their row image (one fragment address instead of four): 119 registers at one stage,
+        // 128 without a spill at two (profiles/r06_syrk_ab.txt: -0.09 ms per evaluation).  The hand-counted form of the loop
+        // is not used for it: beside the 64 loads of the C tile the compiler spills accumulators around the loop.
         constexpr bool F64 = sizeof(T) == 8;
-        constexpr int PF = OP == OP_SYRK ? (F64 ? 1 : 2) : (TM == 64 ? (F64 ? 2 : 4) : 2);
+#ifndef LCGP_SYRK_PF
+#define LCGP_SYRK_PF 2
+#endif
+        constexpr int PF = OP == OP_SYRK ? (F64 ? LCGP_SYRK_PF : 2) : (TM == 64 ? (F64 ? 2 : 4) : 2);
         constexpr int NPC = EPT * (int)sizeof(T) / 16;      // 16-byte pieces per lane, operand and stage
 #ifndef LCGP_NO_COUNTED_PREFETCH
-        constexpr bool COUNTED = !PRELOAD_C && PF == 2 && (NPC == 1 || NPC == 2);
+#ifdef LCGP_SYRK_COUNTED
+        constexpr bool COUNTED = PF == 2 && (NPC == 1 || NPC == 2) && (!PRELOAD_C || F64);
+#else
+        constexpr bool COUNTED = PF == 2 && (NPC == 1 || NPC == 2) && !PRELOAD_C;
+#endif
 #else
         constexpr bool COUNTED = false;
 #endif
@@ -1045,6 +1154,14 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, const int lin /*blo
             typedef typename Piece<T>::v pc_t;
             constexpr int NL = 2 * NPC;                     // loads per register set
             pc_t qa[PF][NPC], qb[PF][NPC];
+            auto put_ap = [&](T* S, const pc_t (&reg)[NPC]) {
+                if constexpr (ROWS_A) store_stage_rows_p<TM, NT>((double*)S, (const Piece<double>::v (&)[NPC])reg, tid);
+                else store_stage_p<T, LA, TM, NT>(S, reg, tid);
+            };
+            auto put_bp = [&](T* S, const pc_t (&reg)[NPC]) {
+                if constexpr (ROWS_B) store_stage_rows_p<TM, NT>((double*)S, (const Piece<double>::v (&)[NPC])reg, tid);
+                else store_stage_p<T, LB, TM, NT>(S, reg, tid);
+            };
             const unsigned voffA = stage_lane_offset<T, LA, TM, NT>(g.ldA, tid), voffB = stage_lane_offset<T, LB, TM, NT>(g.ldB, tid);
             // NO control flow between an asm load and the wait that covers it: at a join the compiler may move a value to
             // another register, and a move placed behind the asm copies the register before the data has arrived.  The number
@@ -1063,16 +1180,13 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, const int lin /*blo
             for (; s + 2 * PF <= nst; s += PF) {
 #pragma unroll
                 for (int h = 0; h < PF; ++h) {
-                    const int buf = h & 1;
-#ifndef LCGP_EXP
-#define LCGP_EXP 0
-#endif
+                    const int buf = (PF & 1) ? ((s + h) & 1) : (h & 1);
                     // (LCGP_EXP: destructive timing experiments, never in a product build -- 1: no operand loads, 2: no LDS
                     // stores / barrier, 8: no MFMA stage; results are garbage)
                     if constexpr (!(LCGP_EXP & 1)) vm_wait_set<(PF - 1) * NL>(qa[h], qb[h]);
                     if constexpr (!(LCGP_EXP & 2)) {
-                        store_stage_p<T, LA, TM, NT>(As + buf * KT * LD, qa[h], tid);
-                        store_stage_p<T, LB, TM, NT>(Bs + buf * KT * LD, qb[h], tid);
+                        put_ap(As + buf * KT * LD, qa[h]);
+                        put_bp(Bs + buf * KT * LD, qb[h]);
                         __syncthreads();
                     }
                     const int kt = (s + h + PF) / SPT, ks = ((s + h + PF) % SPT) * KT;
@@ -1087,22 +1201,23 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, const int lin /*blo
             // the last PF stages (s = nst - PF here): nothing left to fetch, the sets in flight are waited for together
 #pragma unroll
             for (int h = 0; h < PF; ++h) {
-                const int buf = h & 1;
+                const int buf = (PF & 1) ? ((s + h) & 1) : (h & 1);
                 vm_wait_set<0>(qa[h], qb[h]);
-                store_stage_p<T, LA, TM, NT>(As + buf * KT * LD, qa[h], tid);
-                store_stage_p<T, LB, TM, NT>(Bs + buf * KT * LD, qb[h], tid);
+                put_ap(As + buf * KT * LD, qa[h]);
+                put_bp(Bs + buf * KT * LD, qb[h]);
                 __syncthreads();
                 if (wave_live(s + h)) compute_stage(buf);
             }
             // (nothing the asm loaded is outstanding here: the last stored set was waited for with vmcnt(0))
         } else {
         T ra[PF][EPT], rb[PF][EPT];
+        const unsigned uoffA = stage_lane_offset<T, LA, TM, NT>(g.ldA, tid), uoffB = stage_lane_offset<T, LB, TM, NT>(g.ldB, tid);
 #pragma unroll
         for (int h = 0; h < PF; ++h) {
             if (h < nst) {
                 const int kt = h / SPT, ks = (h % SPT) * KT;
-                load_stage<T, LA, TM, NT>(A0 + (ptrdiff_t)kt * dA, g.ldA, ks, ra[h], tid);
-                load_stage<T, LB, TM, NT>(B0 + (ptrdiff_t)kt * dB, g.ldB, ks, rb[h], tid);
+                load_stage_u<T, LA, TM, NT>(A0 + (ptrdiff_t)kt * dA, g.ldA, ks, ra[h], uoffA);
+                load_stage_u<T, LB, TM, NT>(B0 + (ptrdiff_t)kt * dB, g.ldB, ks, rb[h], uoffB);
             }
         }
         for (int s = 0; s < nst; s += PF) {
@@ -1110,13 +1225,15 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, const int lin /*blo
             for (int h = 0; h < PF; ++h) {       // static register index h; LDS buffer (s + h) & 1
                 if (s + h < nst) {
                     const int buf = (PF & 1) ? ((s + h) & 1) : (h & 1);
-                    store_stage<T, LA, TM, NT>(As + buf * KT * LD, ra[h], tid);
-                    store_stage<T, LB, TM, NT>(Bs + buf * KT * LD, rb[h], tid);
+                    if constexpr (!(LCGP_EXP & 128)) {
+                    put_a(As + buf * KT * LD, ra[h]);
+                    put_b(Bs + buf * KT * LD, rb[h]);
                     __syncthreads();
-                    if (s + h + PF < nst) {
+                    }
+                    if (!(LCGP_EXP & 64) && s + h + PF < nst) {
                         const int kt = (s + h + PF) / SPT, ks = ((s + h + PF) % SPT) * KT;
-                        load_stage<T, LA, TM, NT>(A0 + (ptrdiff_t)kt * dA, g.ldA, ks, ra[h], tid);
-                        load_stage<T, LB, TM, NT>(B0 + (ptrdiff_t)kt * dB, g.ldB, ks, rb[h], tid);
+                        load_stage_u<T, LA, TM, NT>(A0 + (ptrdiff_t)kt * dA, g.ldA, ks, ra[h], uoffA);
+                        load_stage_u<T, LB, TM, NT>(B0 + (ptrdiff_t)kt * dB, g.ldB, ks, rb[h], uoffB);
                     }
                     if (wave_live(s + h)) compute_stage(buf);
                 }
@@ -1130,18 +1247,18 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, const int lin /*blo
         for (int ni = 0; ni < MIN; ++ni)
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const int row = wm0 + mi * 16 + Mfma<T>::row(lane, e);
-                const int col = wn0 + ni * 16 + (lane & 15);
-                T* dst = Ct + (size_t)row * g.ldC + col;
+                const unsigned dvoff = cvoff + ni * 16 * (unsigned)sizeof(T), dsoff = c_soff(mi, e);
                 if constexpr (OP == OP_SYRK && TM == 128) {
-                    if (g.skipq && bid + g.t0 == 0 && row < TS && col < TS) continue;
+                    if (g.skipq && bid + g.t0 == 0 && wm0 + mi * 16 + Mfma<T>::row(lane, e) < TS && wn0 + ni * 16 + (lane & 15) < TS)
+                        continue;
                 }
                 if constexpr (PRELOAD_C) {
-                    *dst = (T)acc[mi][ni][e];
+                    if constexpr (LCGP_EXP & 32) { if (acc[mi][ni][e] == (T)1.2345e-300) BufIo<T>::store((T)acc[mi][ni][e], crs, dvoff, dsoff); } else
+                    BufIo<T>::store((T)acc[mi][ni][e], crs, dvoff, dsoff);
                 } else {
                     double v = alpha * (double)acc[mi][ni][e];
-                    if (accumulate) v += (double)*dst;
-                    *dst = (T)v;
+                    if (accumulate) v += (double)BufIo<T>::load(crs, dvoff, dsoff);
+                    BufIo<T>::store((T)v, crs, dvoff, dsoff);
                 }
             }
     if constexpr (OP == OP_LAUUM && TM == 128) {
