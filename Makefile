@@ -19,7 +19,13 @@ $(LIB): $(SRC) $(HDR) $(SCHED)
 tests/native/test_kernels: tests/native/test_kernels.cpp $(LIB) $(HDR)
 	$(HIPCC) $(CXXFLAGS) -o $@ tests/native/test_kernels.cpp -Llcgp_amd -llcgp_hip -Wl,-rpath,'$$ORIGIN/../../lcgp_amd'
 
-clean:
-	rm -f $(LIB) tests/native/test_kernels
+# every native caller of the C ABI outside the test driver (signature drift shows up here, not at run time)
+tools/graph_test: tools/graph_test.cpp $(LIB) $(HDR)
+	$(HIPCC) $(CXXFLAGS) -o $@ tools/graph_test.cpp -Llcgp_amd -llcgp_hip -Wl,-rpath,'$$ORIGIN/../lcgp_amd'
 
-.PHONY: all clean
+tools: tools/graph_test
+
+clean:
+	rm -f $(LIB) tests/native/test_kernels tools/graph_test
+
+.PHONY: all clean tools

@@ -2499,7 +2499,7 @@ struct PlanHeader {
     int dtype, n, nb, q, with_inverse;
     int nlaunch;
     int inverse_done;          // what the plan leaves behind the factorisation: 0 = L, 1 = and L^-1, 2 = and A^-1
-    int num_cu;
+    int reserved;              // (zero; the plan is host-only: nothing in it depends on the device)
     lcgp_sched sched;
     size_t off_launch, bytes;
 };
@@ -2537,12 +2537,6 @@ inline size_t make_plan(int dtype, int n, int q, bool with_inverse, const lcgp_s
     h.nlaunch = (int)plan.launches.size();
     h.inverse_done = inverse_done;
     h.sched = sc;
-    int dev = 0, ncu = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
-        ncu < 1)
-        ncu = 256;
-    (void)hipGetLastError();
-    h.num_cu = ncu;
     h.off_launch = (sizeof(PlanHeader) + 255) & ~size_t(255);
     h.bytes = (h.off_launch + sizeof(lcgp_fill::Launch) * h.nlaunch + 255) & ~size_t(255);
     if (vec) { vec->resize(h.bytes); out = vec->data(); }

@@ -13,6 +13,8 @@ the production path is exercised on a single-GPU test box.
 """
 from __future__ import annotations
 
+import threading
+
 import numpy as np
 
 
@@ -54,7 +56,11 @@ def local_components(q: int, rank: int, world: int):
     return list(range(rank, q, world))
 
 
-_PINNED = {}      # device index -> ONE growable pinned float64 row for the device-to-host copy of an evaluation / prediction
+
+# per host thread: device index -> ONE growable pinned float64 row for the device-to-host copy of an evaluation / prediction
+# (thread-local: the stream synchronisation below releases the GIL, and two models evaluated from two threads on one device
+# would otherwise overwrite each other's row between the copy and the read)
+_TLS = threading.local()
 
 
 def reduce_to_host(t, group=None):
@@ -74,9 +80,12 @@ def reduce_to_host(t, group=None):
         # memory of a serving loop with varying prediction batch sizes stays bounded by the largest one) and one stream
         # synchronisation: no pageable staging buffer and no allocation per evaluation
         n = t.numel()
-        pin = _PINNED.get(t.device.index)
+        rows = getattr(_TLS, 'rows', None)
+        if rows is None:
+            rows = _TLS.rows = {}
+        pin = rows.get(t.device.index)
         if pin is None or pin.numel() < n:
-            pin = _PINNED[t.device.index] = torch.empty(max(n, 256), dtype=torch.float64).pin_memory()
+            pin = rows[t.device.index] = torch.empty(max(n, 256), dtype=torch.float64).pin_memory()
         pin[:n].copy_(t.reshape(-1), non_blocking=True)
         torch.cuda.current_stream(t.device).synchronize()
         return pin[:n].numpy().reshape(tuple(t.shape)).copy()

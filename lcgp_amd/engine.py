@@ -100,16 +100,15 @@ class HotPathEngine:
         return None if self._sched_obj is None else C.byref(self._sched_obj)
 
     def _build_plan(self, with_inverse):
-        """the launch plan of the factorisation for the current schedule as a numpy byte block (lcgp_plan_build); built inside
-        the engine's device context: the plan records the CU count of the CURRENT device"""
+        """the launch plan of the factorisation for the current schedule as a numpy byte block (lcgp_plan_build): host-only,
+        a function of (dtype, n, q_local, with_inverse, schedule) and nothing else"""
         key = bool(with_inverse)
         nbytes = C.c_size_t(0)
-        with self.torch.cuda.device(self.device):
-            _hip.check(self.lib.lcgp_plan_bytes(self.dtype, self.n, self.q_local, int(key), self._sched(), C.byref(nbytes)),
-                       "lcgp_plan_bytes")
-            host = np.zeros(int(nbytes.value), dtype=np.uint8)
-            _hip.check(self.lib.lcgp_plan_build(self.dtype, self.n, self.q_local, int(key), self._sched(),
-                                                C.c_void_p(host.ctypes.data), nbytes), "lcgp_plan_build")
+        _hip.check(self.lib.lcgp_plan_bytes(self.dtype, self.n, self.q_local, int(key), self._sched(), C.byref(nbytes)),
+                   "lcgp_plan_bytes")
+        host = np.zeros(int(nbytes.value), dtype=np.uint8)
+        _hip.check(self.lib.lcgp_plan_build(self.dtype, self.n, self.q_local, int(key), self._sched(),
+                                            C.c_void_p(host.ctypes.data), nbytes), "lcgp_plan_build")
         return host
 
     def plan(self, with_inverse=True):

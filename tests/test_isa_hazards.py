@@ -79,3 +79,49 @@ def test_barrier_checker_flags_the_pattern_hipcc_emitted():
 @pytest.mark.skipif(shutil.which('hipcc') is None, reason='needs hipcc')
 def test_every_kernel_barrier_waits_for_lds_writes():
     assert cbw.main() == 0
+
+
+# ---- hand-counted operand prefetch: nothing may touch an asm-loaded register before the explicit wait ----
+spec3 = importlib.util.spec_from_file_location('check_counted_prefetch', os.path.join(ROOT, 'tools', 'check_counted_prefetch.py'))
+ccp = importlib.util.module_from_spec(spec3)
+spec3.loader.exec_module(ccp)
+
+
+def test_counted_prefetch_checker_flags_a_copy_behind_an_asm_load():
+    """what hipcc made of a prefetch prologue with a conditional load (round 6, while the prefetch was written): the
+    loaded quad is moved to another register right behind the asm, before the data has arrived"""
+    bad = """
+	;;#ASMSTART
+	global_load_dwordx4 v[16:19], v98, s[6:7] offset:0
+	;;#ASMEND
+	v_mov_b32_e32 v86, v16
+	;;#ASMSTART
+	s_waitcnt vmcnt(0)
+	;;#ASMEND
+	ds_write_b128 v100, v[86:89]
+""".splitlines()
+    n, problems = ccp.check(bad)
+    assert n == 1 and problems
+    good = """
+	;;#ASMSTART
+	global_load_dwordx4 v[16:19], v98, s[6:7] offset:0
+	;;#ASMEND
+	;;#ASMSTART
+	global_load_dwordx4 v[20:23], v98, s[6:7] offset:512
+	;;#ASMEND
+	v_add_u32_e32 v99, 1, v98
+	;;#ASMSTART
+	s_waitcnt vmcnt(1)
+	;;#ASMEND
+	ds_write_b128 v100, v[16:19]
+""".splitlines()
+    n, problems = ccp.check(good)
+    assert n == 2 and not problems
+    # the younger load is still in flight behind vmcnt(1)
+    early = good[:-1] + ['\tds_write_b128 v100, v[20:23]']
+    assert ccp.check(early)[1]
+
+
+@pytest.mark.skipif(shutil.which('hipcc') is None, reason='needs hipcc')
+def test_no_kernel_touches_a_prefetched_register_before_its_wait():
+    assert ccp.main() == 0
