@@ -64,7 +64,7 @@ def stage_times(m, reps=3):
     for _ in range(reps):
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(5)]
         ev[0].record(st)
-        _hip.check(lib.lcgp_kernel_build(sp, *args, C.c_void_p(eng.x.data_ptr()), C.c_void_p(0 if eng.sr is None else eng.sr.data_ptr()),
+        _hip.check(lib.lcgp_kernel_build(sp, eng.dtype, eng.kernel_id, *args[1:], C.c_void_p(eng.x.data_ptr()), C.c_void_p(0 if eng.sr is None else eng.sr.data_ptr()),
                                          C.c_void_p(eng.theta_dev.data_ptr()), ws), 'build')
         ev[1].record(st)
         _hip.check(lib.lcgp_potrf_logdet(sp, *args, ws, None, None, eng._sched(), eng.plan(False)), 'potrf')

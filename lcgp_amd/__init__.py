@@ -3,7 +3,7 @@
 Same public surface as the reference package (`src/lcgp/__init__.py:13`): LCGP, Matern32, test.
 """
 from .lcgp import LCGP
-from .covmat import Matern32
+from .covmat import Matern32, SquaredExponential
 from . import evaluation
 
 __version__ = "0.1.0"

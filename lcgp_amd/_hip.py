@@ -18,6 +18,7 @@ HDR_PATH = os.path.join(_ROOT, "include", "lcgp_hip.h")
 SCHED_PATH = os.path.join(_HERE, "csrc", "fill_sched.h")
 
 F64, F32 = 0, 1
+KERNELS = {"matern32": 0, "se": 1}      # include/lcgp_hip.h: LCGP_KERNEL_MATERN32 / LCGP_KERNEL_SE (an extension, parity unpinned)
 
 
 class Sched(C.Structure):
@@ -41,7 +42,8 @@ SIGNATURES = {
     "lcgp_workspace_bytes": (_i, [_i, _i, _i, _i, _i, C.POINTER(C.c_size_t)]),
     "lcgp_predict_scratch_bytes": (_i, [_i, _i, _i, _i, C.POINTER(C.c_size_t)]),
     "lcgp_matern32": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, C.POINTER(_d), _d, _d, _i, _vp]),
-    "lcgp_kernel_build": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
+    "lcgp_covmat": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, C.POINTER(_d), _d, _d, _i, _vp]),
+    "lcgp_kernel_build": (_i, [_vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "lcgp_potrf_logdet": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _sp, _vp]),
     "lcgp_potri": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _sp]),
     "lcgp_trtri": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _sp]),
@@ -49,12 +51,12 @@ SIGNATURES = {
     "lcgp_lauum_clock": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "lcgp_fetch_matrix": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _i, _i, _vp]),
     "lcgp_fetch_vector": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _i, _i, _vp]),
-    "lcgp_nll_grad": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _sp, _vp]),
+    "lcgp_nll_grad": (_i, [_vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _sp, _vp]),
     "lcgp_plan_bytes": (_i, [_i, _i, _i, _i, _sp, C.POINTER(C.c_size_t)]),
     "lcgp_plan_build": (_i, [_i, _i, _i, _i, _sp, _vp, C.c_size_t]),
     "lcgp_plan_info": (_i, [_vp, C.POINTER(_i), C.POINTER(_i)]),
     "lcgp_pack_partial": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
-    "lcgp_predict": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp, _i, _vp, _vp, _vp, _i]),
+    "lcgp_predict": (_i, [_vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp, _i, _vp, _vp, _vp, _i]),
 }
 
 _lib = None

@@ -1,4 +1,5 @@
-"""Matern32 with the reference's signature (covmat.py:5-55), evaluated by the HIP kernel `cross_kernel`."""
+"""Matern32 with the reference's signature (covmat.py:5-55), evaluated by the HIP kernel `cross_kernel`; and the
+squared-exponential product kernel BASELINE.json's north star names (the reference has none: an extension, parity unpinned)."""
 from __future__ import annotations
 
 import numpy as np
@@ -11,7 +12,7 @@ def _as2d(a):
     return np.asarray(a, dtype=np.float64)
 
 
-def Matern32(x1, x2, llmb, llmb0, lnug, diag_only: bool = False):
+def Matern32(x1, x2, llmb, llmb0, lnug, diag_only: bool = False, *, _kernel: str = 'matern32'):
     """
     Returns the Matern 3/2 covariance matrix (separable product form, no sqrt(3) factor).
 
@@ -36,4 +37,13 @@ def Matern32(x1, x2, llmb, llmb0, lnug, diag_only: bool = False):
     nug = float(np.asarray(_as2d(lnug)).reshape(-1)[0])
     same = (x1.shape == x2.shape) and bool(np.all(x1 == x2))
     from .engine import matern32_device
-    return torch.as_tensor(matern32_device(x1, x2, ell, scale, nug, same))
+    return torch.as_tensor(matern32_device(x1, x2, ell, scale, nug, same, kernel=_kernel))
+
+
+def SquaredExponential(x1, x2, llmb, llmb0, lnug, diag_only: bool = False):
+    """
+    The squared-exponential product kernel with Matern32's signature and nugget / scale structure:
+        C = scale ((1 - nt) exp(-1/2 sum_j ((x1_j - x2_j) / llmb_j)^2) + nt [x1 is x2]),   nt = lnug / (1 + lnug).
+    The reference has no such kernel (covmat.py:5-55 holds Matern32 only); `LCGP(..., kernel='se')` uses it.
+    """
+    return Matern32(x1, x2, llmb, llmb0, lnug, diag_only, _kernel='se')

@@ -17,12 +17,13 @@
 #include <stdio.h>
 #include <string.h>
 #include <math.h>
+#include <type_traits>
 #include <vector>
 
 #include "../../include/lcgp_hip.h"
 #include "fill_sched.h"
 
-#define LCGP_VERSION 400
+#define LCGP_VERSION 500
 
 namespace {
 
@@ -53,6 +54,7 @@ inline int round_up(int a, int b) { return (a + b - 1) / b * b; }
 // ---------------------------------------------------------------------------------------------------
 struct Ws {
     int n, npad, nb, d, p, q;
+    int kern = 0;        // covariance kernel (lcgp_hip.h: LCGP_KERNEL_MATERN32 / LCGP_KERNEL_SE)
     size_t esz;
     size_t mat;          // elements per matrix
     char* base;
@@ -200,7 +202,9 @@ __device__ __forceinline__ float exp_nonpos(float x) { return __expf(x); }
 //   C0 = prod_j (1 + S_j) exp(-sum_j S_j),  S_j = |x_i,j/ell_j - x_i',j/ell_j|      (covmat.py:35-53)
 // One 64x64 lower tile per workgroup; x rows/cols staged in LDS already divided by ell.
 // ---------------------------------------------------------------------------------------------------
-template <typename T, int DD /* >= d: the per-dimension loop is unrolled to DD */>
+// KERN: 0 = the reference's separable Matern-3/2 product (covmat.py:31-55), 1 = squared-exponential product kernel
+//   C0 = exp(-1/2 sum_j S_j^2)   (no counterpart in the reference: BASELINE.json's north star names it; parity unpinned)
+template <typename T, int DD /* >= d: the per-dimension loop is unrolled to DD */, int KERN>
 __global__ __launch_bounds__(256) void build_kernel(T* __restrict__ M, size_t mat, int n, int npad, int d, int p,
                                                     const T* __restrict__ x, const T* __restrict__ sr,
                                                     const double* __restrict__ theta, int ntile,
@@ -279,9 +283,14 @@ __global__ __launch_bounds__(256) void build_kernel(T* __restrict__ M, size_t ma
             for (int a = 0; a < 4; ++a)
 #pragma unroll
                 for (int b = 0; b < 4; ++b) {
-                    const T sd = fabs(xa[a] - xb[b]);
-                    poly[a][b] = fma(poly[a][b], sd, poly[a][b]);
-                    ssum[a][b] -= sd;
+                    if constexpr (KERN == 0) {
+                        const T sd = fabs(xa[a] - xb[b]);
+                        poly[a][b] = fma(poly[a][b], sd, poly[a][b]);
+                        ssum[a][b] -= sd;
+                    } else {
+                        const T df = xa[a] - xb[b];
+                        ssum[a][b] = fma((T)-0.5 * df, df, ssum[a][b]);
+                    }
                 }
         }
     };
@@ -326,7 +335,7 @@ __global__ __launch_bounds__(256) void build_kernel(T* __restrict__ M, size_t ma
 // Parameters come either by value (host call, lcgp_matern32) or from a device theta row (predict).
 struct ThetaArg { double v[DWIDE + 2]; };
 
-template <typename T>
+template <typename T, int KERN>
 __global__ __launch_bounds__(256) void cross_kernel(T* __restrict__ out, int ldo, int n1, int n2, int d,
                                                     const T* __restrict__ x1, const T* __restrict__ x2,
                                                     ThetaArg tv, const double* __restrict__ thp /*ell[d], scale, nug*/,
@@ -368,9 +377,14 @@ __global__ __launch_bounds__(256) void cross_kernel(T* __restrict__ out, int ldo
         for (int m = 0; m < 16; ++m) {
             const int i = (tid >> 6) * 16 + m;
             for (int jj = 0; jj < dc; ++jj) {
-                double sd = fabs(xr[i][jj] - xc[j][jj]);
-                poly[m] *= 1.0 + sd;
-                ssum[m] -= sd;
+                if constexpr (KERN == 0) {
+                    double sd = fabs(xr[i][jj] - xc[j][jj]);
+                    poly[m] *= 1.0 + sd;
+                    ssum[m] -= sd;
+                } else {
+                    const double df = xr[i][jj] - xc[j][jj];
+                    ssum[m] = fma(-0.5 * df, df, ssum[m]);
+                }
             }
         }
     }
@@ -1926,7 +1940,7 @@ __device__ __forceinline__ void gsig_body(int a, int k, int n, int npad, int d, 
 // whose error is D C (error of z): small exactly where the difference cancels.  The kernel matrix is recomputed tile by
 // tile here anyway, so the tiles also emit the symmetric matrix-vector partials of c = (C o s s^T) z in double:
 //   cpart[tile][0][i] = sum_j Cs_ij z_j  (rows of the tile),  cpart[tile][1][j] = sum_{i != j} Cs_ij z_i  (its columns)
-template <typename T, int DD>
+template <typename T, int DD, int KERN>
 __global__ __launch_bounds__(256) void grad_kernel(const T* __restrict__ V, size_t mat, int n, int npad, int d, int p,
                                                    const T* __restrict__ x, const T* __restrict__ sr,
                                                    const T* __restrict__ z, const double* __restrict__ theta,
@@ -2013,11 +2027,17 @@ __global__ __launch_bounds__(256) void grad_kernel(const T* __restrict__ V, size
             for (int jj = 0; jj < DD; ++jj) {
                 double xcj;
                 if constexpr (HOIST) xcj = xcv[h][jj]; else xcj = xc[j][jj];
-                const double s = fabs(xr[i][jj] - xcj);
-                sv[jj] = s;
-                pre[jj] = prod;
-                prod = fma(prod, s, prod);
-                ssum -= s;
+                if constexpr (KERN == 0) {
+                    const double s = fabs(xr[i][jj] - xcj);
+                    sv[jj] = s;
+                    pre[jj] = prod;
+                    prod = fma(prod, s, prod);
+                    ssum -= s;
+                } else {            // squared exponential: dC0/d ell_j = C0 S_j^2 / ell_j, no polynomial factor
+                    const double s = xr[i][jj] - xcj;
+                    sv[jj] = s;
+                    ssum = fma(-0.5 * s, s, ssum);
+                }
             }
             const double ex = exp_nonpos(ssum);
             const double ge = G * ex;
@@ -2029,8 +2049,12 @@ __global__ __launch_bounds__(256) void grad_kernel(const T* __restrict__ V, size
             double suf = 1.0;
 #pragma unroll
             for (int jj = DD - 1; jj >= 0; --jj) {
-                acc[jj] = fma(ge * (sv[jj] * sv[jj]), pre[jj] * suf, acc[jj]);
-                suf = fma(suf, sv[jj], suf);
+                if constexpr (KERN == 0) {
+                    acc[jj] = fma(ge * (sv[jj] * sv[jj]), pre[jj] * suf, acc[jj]);
+                    suf = fma(suf, sv[jj], suf);
+                } else {
+                    acc[jj] = fma(ge, sv[jj] * sv[jj], acc[jj]);
+                }
             }
             acc[DD] = fma(ge, prod, acc[DD]);
             if (gi == gj) acc[DD + 1] += G;
@@ -2081,7 +2105,7 @@ __global__ __launch_bounds__(256) void grad_kernel(const T* __restrict__ V, size
 //   sum_ij G_ij e^{-sum S} S_j^2 prod_{i != j} (1 + S_i)  =  sum_ij ge_ij S_j^2 (prod_ij / (1 + S_j)),
 // one accumulator at a time (per-thread accumulators for all d dimensions would not fit the register file; the division
 // replaces the prefix/suffix products of the narrow kernels).  Per-tile partial sums have stride d + 2.
-template <typename T>
+template <typename T, int KERN>
 __global__ __launch_bounds__(256) void grad_kernel_wide(const T* __restrict__ V, size_t mat, int n, int npad, int d, int p,
                                                         const T* __restrict__ x, const T* __restrict__ sr,
                                                         const T* __restrict__ z, const double* __restrict__ theta,
@@ -2140,9 +2164,14 @@ __global__ __launch_bounds__(256) void grad_kernel_wide(const T* __restrict__ V,
                 const int i = (tid >> 5) * 8 + m, j = j0 + h;
                 double pr = prodT[2 * m + h], ss = geT[2 * m + h];
                 for (int jj = 0; jj < DMAX; ++jj) {
-                    const double s = fabs(xr[i][jj] - xc[j][jj]);
-                    pr = fma(pr, s, pr);
-                    ss -= s;
+                    if constexpr (KERN == 0) {
+                        const double s = fabs(xr[i][jj] - xc[j][jj]);
+                        pr = fma(pr, s, pr);
+                        ss -= s;
+                    } else {
+                        const double s = xr[i][jj] - xc[j][jj];
+                        ss = fma(-0.5 * s, s, ss);
+                    }
                 }
                 prodT[2 * m + h] = pr;
                 geT[2 * m + h] = ss;
@@ -2191,7 +2220,8 @@ __global__ __launch_bounds__(256) void grad_kernel_wide(const T* __restrict__ V,
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
                     const double s = fabs(xr[(tid >> 5) * 8 + m][jj] - xc[j0 + h][jj]);
-                    a = fma(geT[2 * m + h] * (s * s), prodT[2 * m + h] / (1.0 + s), a);
+                    if constexpr (KERN == 0) a = fma(geT[2 * m + h] * (s * s), prodT[2 * m + h] / (1.0 + s), a);
+                    else a = fma(geT[2 * m + h], s * s, a);
                 }
             a = wave_sum(a);
             if (lane == 0) red[wave][d0 + jj] = a;
@@ -2377,9 +2407,12 @@ __global__ __launch_bounds__(64) void pred_reduce_kernel(const T* __restrict__ X
 template <typename T, int DD>
 void launch_build(hipStream_t st, const Ws& w, dim3 grid, const void* x, const void* sr, const double* theta, const void* Y) {
     // with Y (the NLL path) the launch also zeroes the log-determinant and status words of the components
-    hipLaunchKernelGGL((build_kernel<T, DD>), grid, dim3(256), 0, st, (T*)(w.base + w.off_M), w.mat, w.n, w.npad, w.d, w.p,
-                       (const T*)x, (const T*)sr, theta, w.ntile_lower, (const T*)Y, (T*)(w.base + w.off_b),
-                       Y ? (double*)(w.base + w.off_logdet) : nullptr, Y ? (int*)(w.base + w.off_info) : nullptr);
+    auto go = [&](auto kern) {
+        hipLaunchKernelGGL((build_kernel<T, DD, decltype(kern)::value>), grid, dim3(256), 0, st, (T*)(w.base + w.off_M), w.mat, w.n,
+                           w.npad, w.d, w.p, (const T*)x, (const T*)sr, theta, w.ntile_lower, (const T*)Y, (T*)(w.base + w.off_b),
+                           Y ? (double*)(w.base + w.off_logdet) : nullptr, Y ? (int*)(w.base + w.off_info) : nullptr);
+    };
+    if (w.kern == 0) go(std::integral_constant<int, 0>{}); else go(std::integral_constant<int, 1>{});
 }
 
 template <typename T>
@@ -2700,10 +2733,13 @@ template <typename T, int DD>
 void launch_grad(hipStream_t st, const Ws& w, const void* x, const void* sr, const double* theta, const void* Y,
                  double* out) {
     // (float32: the noise gradient comes from c = (C o s s^T) z after this launch, so no extra blocks here)
-    hipLaunchKernelGGL((grad_kernel<T, DD>), dim3(w.ntile_lower + (sizeof(T) == 4 ? 0 : w.p), w.q), dim3(256), 0, st,
-                       (const T*)(w.base + w.off_V), w.mat, w.n, w.npad, w.d, w.p, (const T*)x, (const T*)sr,
-                       (const T*)(w.base + w.off_z), theta, (double*)(w.base + w.off_part), w.ntile_lower, (const T*)Y,
-                       (const T*)(w.base + w.off_b), out, (double*)(w.base + w.off_cpart));
+    auto go = [&](auto kern) {
+        hipLaunchKernelGGL((grad_kernel<T, DD, decltype(kern)::value>), dim3(w.ntile_lower + (sizeof(T) == 4 ? 0 : w.p), w.q),
+                           dim3(256), 0, st, (const T*)(w.base + w.off_V), w.mat, w.n, w.npad, w.d, w.p, (const T*)x, (const T*)sr,
+                           (const T*)(w.base + w.off_z), theta, (double*)(w.base + w.off_part), w.ntile_lower, (const T*)Y,
+                           (const T*)(w.base + w.off_b), out, (double*)(w.base + w.off_cpart));
+    };
+    if (w.kern == 0) go(std::integral_constant<int, 0>{}); else go(std::integral_constant<int, 1>{});
 }
 
 template <typename T>
@@ -2738,11 +2774,15 @@ int do_nll_grad(hipStream_t st, const Ws& w, const lcgp_sched& sc, const void* x
     else if (w.d <= 10) launch_grad<T, 10>(st, w, x, sr, theta, Y, out);
     else if (w.d <= 16) launch_grad<T, 16>(st, w, x, sr, theta, Y, out);
     else if (w.d <= DMAX) launch_grad<T, DMAX>(st, w, x, sr, theta, Y, out);
-    else
-        hipLaunchKernelGGL((grad_kernel_wide<T>), dim3(w.ntile_lower + (sizeof(T) == 4 ? 0 : w.p), w.q), dim3(256), 0, st,
-                           (const T*)(w.base + w.off_V), w.mat, w.n, w.npad, w.d, w.p, (const T*)x, (const T*)sr,
-                           (const T*)(w.base + w.off_z), theta, (double*)(w.base + w.off_part), w.ntile_lower, (const T*)Y,
-                           (const T*)(w.base + w.off_b), out, (double*)(w.base + w.off_cpart));
+    else {
+        auto go = [&](auto kern) {
+            hipLaunchKernelGGL((grad_kernel_wide<T, decltype(kern)::value>), dim3(w.ntile_lower + (sizeof(T) == 4 ? 0 : w.p), w.q),
+                               dim3(256), 0, st, (const T*)(w.base + w.off_V), w.mat, w.n, w.npad, w.d, w.p, (const T*)x,
+                               (const T*)sr, (const T*)(w.base + w.off_z), theta, (double*)(w.base + w.off_part), w.ntile_lower,
+                               (const T*)Y, (const T*)(w.base + w.off_b), out, (double*)(w.base + w.off_cpart));
+        };
+        if (w.kern == 0) go(std::integral_constant<int, 0>{}); else go(std::integral_constant<int, 1>{});
+    }
     CHECK_LAUNCH("grad_kernel");
     const double* cvec = nullptr;
     if constexpr (sizeof(T) == 4) {
@@ -2805,8 +2845,9 @@ __global__ __launch_bounds__(256) void pack_partial_kernel(int d, int p, int q_l
     }
 }
 
-int check_common(int dtype, int n, int d, int p, int q) {
+int check_common(int dtype, int n, int d, int p, int q, int kernel_id = 0) {
     if (dtype != LCGP_F64 && dtype != LCGP_F32) return bad("dtype must be 0 (f64) or 1 (f32)");
+    if (kernel_id != LCGP_KERNEL_MATERN32 && kernel_id != LCGP_KERNEL_SE) return bad("kernel_id must be 0 (Matern-3/2) or 1 (squared exponential)");
     if (n < 1) return bad("n < 1");
     if (d < 1 || d > DWIDE) return bad("d must be in [1, 126]");
     if (p < 1) return bad("p < 1");
@@ -2820,11 +2861,15 @@ inline int resolve_sched(const lcgp_sched* in, lcgp_sched& out) {
 }
 
 template <typename T>
-int do_matern(hipStream_t st, int n1, int n2, int d, const void* x1, const void* x2, const ThetaArg& th, int same,
+int do_matern(hipStream_t st, int kern, int n1, int n2, int d, const void* x1, const void* x2, const ThetaArg& th, int same,
               void* out) {
     dim3 grid((n2 + TS - 1) / TS, (n1 + TS - 1) / TS);
-    hipLaunchKernelGGL((cross_kernel<T>), grid, dim3(256), 0, st, (T*)out, n2, n1, n2, d, (const T*)x1, (const T*)x2, th,
-                       (const double*)nullptr, same, (const T*)nullptr, n1, n2, 0, (size_t)0);
+    if (kern == 0)
+        hipLaunchKernelGGL((cross_kernel<T, 0>), grid, dim3(256), 0, st, (T*)out, n2, n1, n2, d, (const T*)x1, (const T*)x2, th,
+                           (const double*)nullptr, same, (const T*)nullptr, n1, n2, 0, (size_t)0);
+    else
+        hipLaunchKernelGGL((cross_kernel<T, 1>), grid, dim3(256), 0, st, (T*)out, n2, n1, n2, d, (const T*)x1, (const T*)x2, th,
+                           (const double*)nullptr, same, (const T*)nullptr, n1, n2, 0, (size_t)0);
     CHECK_LAUNCH("cross_kernel");
     return 0;
 }
@@ -2846,8 +2891,12 @@ int do_predict(hipStream_t st, const Ws& w, const void* x, const void* sr, const
     ThetaArg dummy;
     memset(&dummy, 0, sizeof(dummy));
     dim3 grid(w.nb, n0pad / TS, w.q);
-    hipLaunchKernelGGL((cross_kernel<T>), grid, dim3(256), 0, st, X, w.npad, n0, w.n, w.d, (const T*)x0, (const T*)x, dummy,
-                       theta, same, (const T*)sr, n0pad, w.npad, tw, slab);
+    if (w.kern == 0)
+        hipLaunchKernelGGL((cross_kernel<T, 0>), grid, dim3(256), 0, st, X, w.npad, n0, w.n, w.d, (const T*)x0, (const T*)x, dummy,
+                           theta, same, (const T*)sr, n0pad, w.npad, tw, slab);
+    else
+        hipLaunchKernelGGL((cross_kernel<T, 1>), grid, dim3(256), 0, st, X, w.npad, n0, w.n, w.d, (const T*)x0, (const T*)x, dummy,
+                           theta, same, (const T*)sr, n0pad, w.npad, tw, slab);
     CHECK_LAUNCH("cross_kernel");
     GemmArgs g;
     g.A = X; g.B = (const T*)(w.base + w.off_W); g.C = U;
@@ -2908,9 +2957,10 @@ int lcgp_predict_scratch_bytes(int dtype, int n, int q_local, int n0, size_t* by
     return 0;
 }
 
-int lcgp_matern32(void* stream, int dtype, int n1, int n2, int d, const void* x1, const void* x2, const double* ell,
-                  double scale, double nug, int same, void* out) {
+int lcgp_covmat(void* stream, int dtype, int kernel_id, int n1, int n2, int d, const void* x1, const void* x2, const double* ell,
+                double scale, double nug, int same, void* out) {
     if (dtype != LCGP_F64 && dtype != LCGP_F32) return bad("dtype must be 0 (f64) or 1 (f32)");
+    if (kernel_id != LCGP_KERNEL_MATERN32 && kernel_id != LCGP_KERNEL_SE) return bad("kernel_id must be 0 (Matern-3/2) or 1 (squared exponential)");
     if (n1 < 1 || n2 < 1) return bad("n1/n2 < 1");
     if (d < 1 || d > DWIDE) return bad("d must be in [1, 126]");
     if (!x1 || !x2 || !ell || !out) return bad("NULL pointer");
@@ -2920,16 +2970,21 @@ int lcgp_matern32(void* stream, int dtype, int n1, int n2, int d, const void* x1
     th.v[d] = scale;
     th.v[d + 1] = nug;
     hipStream_t st = (hipStream_t)stream;
-    return dtype == LCGP_F64 ? do_matern<double>(st, n1, n2, d, x1, x2, th, same, out)
-                             : do_matern<float>(st, n1, n2, d, x1, x2, th, same, out);
+    return dtype == LCGP_F64 ? do_matern<double>(st, kernel_id, n1, n2, d, x1, x2, th, same, out)
+                             : do_matern<float>(st, kernel_id, n1, n2, d, x1, x2, th, same, out);
+}
+int lcgp_matern32(void* stream, int dtype, int n1, int n2, int d, const void* x1, const void* x2, const double* ell,
+                  double scale, double nug, int same, void* out) {
+    return lcgp_covmat(stream, dtype, LCGP_KERNEL_MATERN32, n1, n2, d, x1, x2, ell, scale, nug, same, out);
 }
 
-int lcgp_kernel_build(void* stream, int dtype, int n, int d, int p, int q_local, const void* x, const void* sr,
+int lcgp_kernel_build(void* stream, int dtype, int kernel_id, int n, int d, int p, int q_local, const void* x, const void* sr,
                       const double* theta, void* workspace) {
-    int rc = check_common(dtype, n, d, p, q_local);
+    int rc = check_common(dtype, n, d, p, q_local, kernel_id);
     if (rc) return rc;
     if (!x || !theta || !workspace) return bad("NULL pointer");
     Ws w = carve(dtype, n, d, p, q_local, workspace);
+    w.kern = kernel_id;
     return dtype == LCGP_F64 ? do_build<double>((hipStream_t)stream, w, x, sr, theta)
                              : do_build<float>((hipStream_t)stream, w, x, sr, theta);
 }
@@ -3036,11 +3091,11 @@ int lcgp_fetch_vector(void* stream, int dtype, int n, int d, int p, int q_local,
     return 0;
 }
 
-int lcgp_nll_grad(void* stream, int dtype, int n, int d, int p, int q_local, const void* x, const void* Y,
+int lcgp_nll_grad(void* stream, int dtype, int kernel_id, int n, int d, int p, int q_local, const void* x, const void* Y,
                   const void* sr, const double* theta, void* workspace, double* out, const lcgp_sched* sched,
                   const void* plan) {
     const void* plan_host = plan;
-    int rc = check_common(dtype, n, d, p, q_local);
+    int rc = check_common(dtype, n, d, p, q_local, kernel_id);
     if (rc) return rc;
     if (!x || !Y || !theta || !workspace || !out) return bad("NULL pointer");
     lcgp_sched sc;
@@ -3052,6 +3107,7 @@ int lcgp_nll_grad(void* stream, int dtype, int n, int d, int p, int q_local, con
         return rc;
     }
     Ws w = carve(dtype, n, d, p, q_local, workspace);
+    w.kern = kernel_id;
     return dtype == LCGP_F64 ? do_nll_grad<double>((hipStream_t)stream, w, sc, x, Y, sr, theta, out, plan_host)
                              : do_nll_grad<float>((hipStream_t)stream, w, sc, x, Y, sr, theta, out, plan_host);
 }
@@ -3098,16 +3154,17 @@ int lcgp_pack_partial(void* stream, int d, int p, int q_local, int q_total, cons
     return 0;
 }
 
-int lcgp_predict(void* stream, int dtype, int n, int d, int p, int q_local, const void* x, const void* sr,
+int lcgp_predict(void* stream, int dtype, int kernel_id, int n, int d, int p, int q_local, const void* x, const void* sr,
                  const double* theta, const void* workspace, int n0, const void* x0, int same, void* scratch,
                  double* ghat, double* gvar, int out_stride) {
-    int rc = check_common(dtype, n, d, p, q_local);
+    int rc = check_common(dtype, n, d, p, q_local, kernel_id);
     if (rc) return rc;
     if (n0 < 1) return bad("n0 < 1");
     if (!x || !theta || !workspace || !x0 || !scratch || !ghat || !gvar) return bad("NULL pointer");
     if (out_stride != 0 && out_stride < n0) return bad("out_stride must be 0 (= n0) or >= n0");
     const int ldo = out_stride ? out_stride : n0;
     Ws w = carve(dtype, n, d, p, q_local, (void*)workspace);
+    w.kern = kernel_id;
     hipStream_t st = (hipStream_t)stream;
     return dtype == LCGP_F64 ? do_predict<double>(st, w, x, sr, theta, n0, x0, same, scratch, ghat, gvar, ldo)
                              : do_predict<float>(st, w, x, sr, theta, n0, x0, same, scratch, ghat, gvar, ldo);

@@ -25,10 +25,11 @@ class HotPathEngine:
     components over all ranks; they place this rank's gradient slots in the vector the ranks all-reduce
     (`evaluate_partial`).  Defaults: a single rank holding components 0 .. q_local-1."""
 
-    def __init__(self, x, Y, sr=None, q_local=1, dtype="float64", device=None, comp_ids=None, q_total=None):
+    def __init__(self, x, Y, sr=None, q_local=1, dtype="float64", device=None, comp_ids=None, q_total=None, kernel="matern32"):
         import torch
         _hip.require_gpu()
         self.lib = _hip.load()
+        self.kernel_id = _hip.KERNELS[kernel]      # covariance kernel of the latent components (the reference: Matern-3/2 only)
         self.torch = torch
         self.dtype_name = "float64" if _DT[dtype] == _hip.F64 else "float32"
         self.dtype = _DT[dtype]
@@ -166,11 +167,11 @@ class HotPathEngine:
     def enqueue(self, stream=None):
         """One pass of the hot path over the resident theta block (asynchronous)."""
         if stream is not None:                    # (inside the device context already)
-            _hip.check(self.lib.lcgp_nll_grad(C.c_void_p(stream.cuda_stream), self.dtype, self.n, self.d, self.p, self.q_local,
+            _hip.check(self.lib.lcgp_nll_grad(C.c_void_p(stream.cuda_stream), self.dtype, self.kernel_id, self.n, self.d, self.p, self.q_local,
                                               *self._nll_args(), self._sched(), self.plan(True)), "lcgp_nll_grad")
             return
         with self.torch.cuda.device(self.device):
-            _hip.check(self.lib.lcgp_nll_grad(self._stream(), self.dtype, self.n, self.d, self.p, self.q_local,
+            _hip.check(self.lib.lcgp_nll_grad(self._stream(), self.dtype, self.kernel_id, self.n, self.d, self.p, self.q_local,
                                               *self._nll_args(), self._sched(), self.plan(True)),
                        "lcgp_nll_grad")
 
@@ -227,7 +228,7 @@ class HotPathEngine:
                 m = min(chunk, n0 - lo)
                 # the nugget term only exists when x0 IS the training set (covmat.py:46-51): then n0 == n and the
                 # diagonal of the full cross matrix falls on rows lo .. lo+m of this chunk
-                _hip.check(self.lib.lcgp_predict(st, self.dtype, self.n, self.d, self.p, self.q_local, xp, srp, thp, wsp, m,
+                _hip.check(self.lib.lcgp_predict(st, self.dtype, self.kernel_id, self.n, self.d, self.p, self.q_local, xp, srp, thp, wsp, m,
                                                  C.c_void_p(x0d.data_ptr() + lo * self.d * x0d.element_size()),
                                                  (1 + lo) if same else 0, scp,
                                                  C.c_void_p(ghat.data_ptr() + 8 * lo), C.c_void_p(gvar.data_ptr() + 8 * lo), n0),
@@ -262,8 +263,9 @@ class HotPathEngine:
             return out.cpu().numpy().astype(np.float64)
 
 
-def matern32_device(x1, x2, ell, scale, nug, same, dtype="float64"):
-    """covmat.py:31-55 on the GPU: returns the (n1, n2) matrix as a numpy float64 array."""
+def matern32_device(x1, x2, ell, scale, nug, same, dtype="float64", kernel="matern32"):
+    """covmat.py:31-55 on the GPU: returns the (n1, n2) matrix as a numpy float64 array (kernel = "se": the squared-exponential
+    product kernel with the same scale / nugget structure, an extension the reference does not have)."""
     import torch
     _hip.require_gpu()
     lib = _hip.load()
@@ -276,8 +278,8 @@ def matern32_device(x1, x2, ell, scale, nug, same, dtype="float64"):
     n2 = b.shape[0]
     out = torch.empty((n1, n2), dtype=tdt, device=dev)
     ell = np.ascontiguousarray(ell, np.float64)
-    _hip.check(lib.lcgp_matern32(C.c_void_p(torch.cuda.current_stream(dev).cuda_stream), dt, n1, n2, d,
+    _hip.check(lib.lcgp_covmat(C.c_void_p(torch.cuda.current_stream(dev).cuda_stream), dt, _hip.KERNELS[kernel], n1, n2, d,
                                  C.c_void_p(a.data_ptr()), C.c_void_p(b.data_ptr()),
                                  ell.ctypes.data_as(C.POINTER(C.c_double)), float(scale), float(nug), int(bool(same)),
-                                 C.c_void_p(out.data_ptr())), "lcgp_matern32")
+                                 C.c_void_p(out.data_ptr())), "lcgp_covmat")
     return out.cpu().numpy().astype(np.float64)

@@ -64,8 +64,13 @@ class LCGP:
     # =============================================================================================
     def __init__(self, y=None, x=None, q=None, var_threshold=None, diag_error_structure=None,
                  parameter_clamp_flag=False, robust_mean=True, submethod='full', rep_standardize_ybar=True,
-                 verbose=False, *, device=None, dtype='float64', process_group=None):
+                 verbose=False, *, device=None, dtype='float64', process_group=None, kernel='matern32'):
         self.verbose = verbose
+        # covariance kernel of the latent components: 'matern32' is the reference's only kernel (covmat.py:5-55); 'se', the
+        # squared-exponential product kernel, is an extension (BASELINE.json's north star names it; parity unpinned)
+        if kernel not in ('matern32', 'se'):
+            raise ValueError("kernel must be 'matern32' or 'se', got %r" % (kernel,))
+        self.kernel = kernel
         self.robust_mean = robust_mean
         self.rep_standardize_ybar = rep_standardize_ybar
         self.parameter_clamp_flag = parameter_clamp_flag
@@ -397,9 +402,9 @@ class LCGP:
             sr = np.sqrt(_np(self.r))
             ybar_used = _np(self.ybar_s if self.rep_standardize_ybar else self.ybar)
             return HotPathEngine(_np(self.x_unique_s), ybar_used * sr[None, :], sr, len(self._local_ks),
-                                 dtype, self._device, comp_ids=self._local_ks, q_total=self.q)
+                                 dtype, self._device, comp_ids=self._local_ks, q_total=self.q, kernel=self.kernel)
         return HotPathEngine(_np(self.x), _np(self.y), None, len(self._local_ks), dtype, self._device,
-                             comp_ids=self._local_ks, q_total=self.q)
+                             comp_ids=self._local_ks, q_total=self.q, kernel=self.kernel)
 
     def _get_engine(self):
         if self._float64_only:           # a float32 model that has given up on float32 (float32_switch_after)

@@ -94,8 +94,12 @@ def softclip_grad(u, lo, hi):
 # --------------------------------------------------------------------------------------
 # covmat.py
 # --------------------------------------------------------------------------------------
-def matern32(x1, x2, llmb, llmb0, lnug, diag_only=False):
-    """covmat.py:5-55.  `llmb`, `llmb0`, `lnug` are the constrained values."""
+def matern32(x1, x2, llmb, llmb0, lnug, diag_only=False, kernel='matern32'):
+    """covmat.py:5-55.  `llmb`, `llmb0`, `lnug` are the constrained values.
+
+    kernel='se': the squared-exponential product kernel C0 = exp(-1/2 sum_j S_j^2) with the same nugget / scale structure.
+    The reference has NO such kernel: this branch restates nothing, it defines the extension the HIP path offers as
+    LCGP_KERNEL_SE (parity unpinned; checked through identities only, tests/test_oracle_identities.py)."""
     x1 = np.asarray(x1, F64)
     x2 = np.asarray(x2, F64)
     assert x1.ndim == 2, 'input x1 should be 2-dimensional, (n_param, dim_param)'
@@ -111,8 +115,11 @@ def matern32(x1, x2, llmb, llmb0, lnug, diag_only=False):
     poly = np.ones_like(logpart)
     for j in range(x1.shape[1]):  # covmat.py:37-41
         s = np.abs(a[:, j][:, None] - b[:, j][None, :])
-        poly *= 1.0 + s
-        logpart -= s
+        if kernel == 'se':
+            logpart -= 0.5 * s * s
+        else:
+            poly *= 1.0 + s
+            logpart -= s
     c0 = poly * np.exp(logpart)
     nt = lnug / (1.0 + lnug)
     same = (x1.shape == x2.shape) and bool(np.all(x1 == x2))  # covmat.py:46-53
@@ -123,14 +130,17 @@ def matern32(x1, x2, llmb, llmb0, lnug, diag_only=False):
     return float(llmb0) * c
 
 
-def matern32_c0_and_s(x, ell):
-    """C0 = prod_j (1+S_j) exp(-sum S_j) and the list of S_j."""
+def matern32_c0_and_s(x, ell, kernel='matern32'):
+    """C0 = prod_j (1+S_j) exp(-sum S_j) and the list of S_j; kernel='se': C0 = exp(-1/2 sum S_j^2)."""
     a = x / ell
     n, d = x.shape
     s_all = np.empty((d, n, n), F64)
     for j in range(d):
         s_all[j] = np.abs(a[:, j][:, None] - a[:, j][None, :])
-    c0 = np.prod(1.0 + s_all, axis=0) * np.exp(-s_all.sum(axis=0))
+    if kernel == 'se':
+        c0 = np.exp(-0.5 * (s_all * s_all).sum(axis=0))
+    else:
+        c0 = np.prod(1.0 + s_all, axis=0) * np.exp(-s_all.sum(axis=0))
     return c0, s_all
 
 
@@ -222,14 +232,14 @@ def expand_lsigma2s(ls2, err_struct):
 # --------------------------------------------------------------------------------------
 # full path NLL, two algebraically identical forms
 # --------------------------------------------------------------------------------------
-def nll_full_eigh(x, y, phi, diag_d, lLmb, lLmb0, ls2_built, lnug):
+def nll_full_eigh(x, y, phi, diag_d, lLmb, lLmb0, ls2_built, lnug, kernel='matern32'):
     """lcgp.py:635-666 restated literally (eigh + dense products) -- the reference algorithm."""
     n = x.shape[0]
     q = phi.shape[1]
     psi_c = phi.T / np.sqrt(np.exp(ls2_built))
     nlp = 0.0
     for k in range(q):
-        ck = matern32(x, x, lLmb[k], lLmb0[k], lnug[k])
+        ck = matern32(x, x, lLmb[k], lLmb0[k], lnug[k], kernel=kernel)
         wk, uk = np.linalg.eigh(ck)
         qk = uk @ (np.diag(1.0 / (diag_d[k] + 1.0 / wk)) @ uk.T)
         pk = psi_c[k][:, None] @ psi_c[k][None, :]
@@ -242,9 +252,9 @@ def nll_full_eigh(x, y, phi, diag_d, lLmb, lLmb0, ls2_built, lnug):
     return float(nlp)
 
 
-def _chol_component(x, ell, scale, nug, dk, b, sr=None):
+def _chol_component(x, ell, scale, nug, dk, b, sr=None, kernel='matern32'):
     """A = I + D (C o sr sr^T); returns L, C0, S, half log det, z = A^-1 b."""
-    c0, s_all = matern32_c0_and_s(x, ell)
+    c0, s_all = matern32_c0_and_s(x, ell, kernel)
     nt = nug / (1.0 + nug)
     n = x.shape[0]
     c = scale * ((1.0 - nt) * c0 + nt * np.eye(n))
@@ -259,7 +269,7 @@ def _chol_component(x, ell, scale, nug, dk, b, sr=None):
     return low, c0, s_all, half_logdet, z
 
 
-def _kernel_param_grads(low, c0, s_all, z, dk, ell, scale, nug, sr=None):
+def _kernel_param_grads(low, c0, s_all, z, dk, ell, scale, nug, sr=None, kernel='matern32'):
     """sum_ij G_ij dC_ij/dtheta with G = sr sr^T o (D/2 A^-1 - z z^T / 2)  (SURVEY A.5)."""
     n = low.shape[0]
     ainv = sla.cho_solve((low, True), np.eye(n))
@@ -270,7 +280,10 @@ def _kernel_param_grads(low, c0, s_all, z, dk, ell, scale, nug, sr=None):
     g_ell = np.empty(len(ell), F64)
     for j in range(len(ell)):
         sj = s_all[j]
-        g_ell[j] = np.sum(gmat * (scale * (1.0 - nt) * c0 * sj * sj / ((1.0 + sj) * ell[j])))
+        if kernel == 'se':      # d/d ell_j exp(-1/2 sum S^2) = C0 S_j^2 / ell_j
+            g_ell[j] = np.sum(gmat * (scale * (1.0 - nt) * c0 * sj * sj / ell[j]))
+        else:
+            g_ell[j] = np.sum(gmat * (scale * (1.0 - nt) * c0 * sj * sj / ((1.0 + sj) * ell[j])))
     tr_g = np.trace(gmat)
     g_c0 = np.sum(gmat * c0)
     g_scale = (1.0 - nt) * g_c0 + nt * tr_g
@@ -278,7 +291,7 @@ def _kernel_param_grads(low, c0, s_all, z, dk, ell, scale, nug, sr=None):
     return g_ell, g_scale, g_nug
 
 
-def nll_grad_full_chol(x, y, phi, diag_d, err_struct, lLmb, lLmb0, ls2, lnug, want_grad=True):
+def nll_grad_full_chol(x, y, phi, diag_d, err_struct, lLmb, lLmb0, ls2, lnug, want_grad=True, kernel='matern32'):
     """Cholesky form of lcgp.py:635-666 + closed-form gradient (A.5).
 
     Returns (nll, dict of gradients w.r.t. the CONSTRAINED parameters).
@@ -297,10 +310,10 @@ def nll_grad_full_chol(x, y, phi, diag_d, err_struct, lLmb, lLmb0, ls2, lnug, wa
     g_ls2_b = n / 2.0 - 0.5 * ysq / sig ** 2
     for k in range(q):
         b = y.T @ (phi[:, k] / sig)
-        low, c0, s_all, half_logdet, z = _chol_component(x, lLmb[k], lLmb0[k], lnug[k], diag_d[k], b)
+        low, c0, s_all, half_logdet, z = _chol_component(x, lLmb[k], lLmb0[k], lnug[k], diag_d[k], b, kernel=kernel)
         nll += half_logdet - float(b @ (b - z)) / (2.0 * diag_d[k])
         if want_grad:
-            ge, gs, gn = _kernel_param_grads(low, c0, s_all, z, diag_d[k], lLmb[k], lLmb0[k], lnug[k])
+            ge, gs, gn = _kernel_param_grads(low, c0, s_all, z, diag_d[k], lLmb[k], lLmb0[k], lnug[k], kernel=kernel)
             g_lLmb[k], g_lLmb0[k], g_lnug[k] = ge, gs, gn
             gb = -(b - z) / diag_d[k]
             g_ls2_b += -0.5 / sig * phi[:, k] * (y @ gb)
@@ -313,7 +326,7 @@ def nll_grad_full_chol(x, y, phi, diag_d, err_struct, lLmb, lLmb0, ls2, lnug, wa
 # --------------------------------------------------------------------------------------
 # replicated path NLL
 # --------------------------------------------------------------------------------------
-def nll_rep_literal(xu_s, ybar_used, ybar_std, use_std, r, phi, diag_d, n, p, lLmb, lLmb0, ls2_built, lnug):
+def nll_rep_literal(xu_s, ybar_used, ybar_std, use_std, r, phi, diag_d, n, p, lLmb, lLmb0, ls2_built, lnug, kernel='matern32'):
     """lcgp.py:554-630 restated step by step (Cholesky of I + d_k R^1/2 C_k R^1/2)."""
     r = np.asarray(r, F64)
     sigma_var_raw = np.exp(ls2_built)
@@ -332,7 +345,7 @@ def nll_rep_literal(xu_s, ybar_used, ybar_std, use_std, r, phi, diag_d, n, p, lL
     bsb = 0.0
     logdet = 0.0
     for k in range(phi.shape[1]):
-        ck = matern32(xu_s, xu_s, lLmb[k], lLmb0[k], lnug[k])
+        ck = matern32(xu_s, xu_s, lLmb[k], lLmb0[k], lnug[k], kernel=kernel)
         b = r * (ybar_used.T @ (sis * phi[:, k]))
         dk = diag_d[k]
         cb = ck @ b
@@ -348,7 +361,7 @@ def nll_rep_literal(xu_s, ybar_used, ybar_std, use_std, r, phi, diag_d, n, p, lL
 
 
 def nll_grad_rep_chol(xu_s, ybar_used, ybar_std, use_std, r, phi, diag_d, err_struct,
-                      lLmb, lLmb0, ls2, lnug, want_grad=True):
+                      lLmb, lLmb0, ls2, lnug, want_grad=True, kernel='matern32'):
     """Same value as `nll_rep_literal`, through the identity
     b^T (C^-1 + D R)^-1 b = (beta^T beta - beta^T A^-1 beta)/D with beta = b / sqrt(r),
     A = I + D (C o sqrt(r) sqrt(r)^T); closed-form gradient w.r.t. constrained parameters.
@@ -371,10 +384,10 @@ def nll_grad_rep_chol(xu_s, ybar_used, ybar_std, use_std, r, phi, diag_d, err_st
     g_ls2_b = n / 2.0 - 0.5 * ysq / sig_eff ** 2
     for k in range(q):
         beta = yeff.T @ (phi[:, k] / sig_eff)
-        low, c0, s_all, half_logdet, z = _chol_component(xu_s, lLmb[k], lLmb0[k], lnug[k], diag_d[k], beta, sr)
+        low, c0, s_all, half_logdet, z = _chol_component(xu_s, lLmb[k], lLmb0[k], lnug[k], diag_d[k], beta, sr, kernel=kernel)
         nll += half_logdet - float(beta @ (beta - z)) / (2.0 * diag_d[k])
         if want_grad:
-            ge, gs, gn = _kernel_param_grads(low, c0, s_all, z, diag_d[k], lLmb[k], lLmb0[k], lnug[k], sr)
+            ge, gs, gn = _kernel_param_grads(low, c0, s_all, z, diag_d[k], lLmb[k], lLmb0[k], lnug[k], sr, kernel=kernel)
             g_lLmb[k], g_lLmb0[k], g_lnug[k] = ge, gs, gn
             gb = -(beta - z) / diag_d[k]
             g_ls2_b += -0.5 / sig_eff * phi[:, k] * (yeff @ gb)
@@ -392,7 +405,8 @@ class OracleLCGP:
 
     def __init__(self, y, x, q=None, var_threshold=None, diag_error_structure=None,
                  parameter_clamp_flag=False, robust_mean=True, submethod='full',
-                 rep_standardize_ybar=True, verbose=False):
+                 rep_standardize_ybar=True, verbose=False, kernel='matern32'):
+        self.kernel = kernel            # 'matern32' = the reference; 'se' = the extension (see matern32())
         self.robust_mean = robust_mean
         self.rep_standardize_ybar = rep_standardize_ybar
         x = np.asarray(x, F64)
@@ -463,11 +477,11 @@ class OracleLCGP:
     def _value_and_constrained_grad(self, want_grad=True):
         if self.submethod == 'full':
             return nll_grad_full_chol(self.x, self.y, self.phi, self.diag_D, self.diag_error_structure,
-                                      self.lLmb, self.lLmb0, self.lsigma2s, self.lnugGPs, want_grad)
+                                      self.lLmb, self.lLmb0, self.lsigma2s, self.lnugGPs, want_grad, kernel=self.kernel)
         ybar_used = self.ybar_s if self.rep_standardize_ybar else self.ybar
         return nll_grad_rep_chol(self.x_unique_s, ybar_used, self.ybar_std, self.rep_standardize_ybar,
                                  self.r, self.phi, self.diag_D, self.diag_error_structure,
-                                 self.lLmb, self.lLmb0, self.lsigma2s, self.lnugGPs, want_grad)
+                                 self.lLmb, self.lLmb0, self.lsigma2s, self.lnugGPs, want_grad, kernel=self.kernel)
 
     def loss(self):
         return self._value_and_constrained_grad(False)[0]
@@ -476,10 +490,10 @@ class OracleLCGP:
         """The literal restatement (eigh form / step-by-step rep form)."""
         lLmb, lLmb0, ls2b, lnug = self.get_param()
         if self.submethod == 'full':
-            return nll_full_eigh(self.x, self.y, self.phi, self.diag_D, lLmb, lLmb0, ls2b, lnug)
+            return nll_full_eigh(self.x, self.y, self.phi, self.diag_D, lLmb, lLmb0, ls2b, lnug, kernel=self.kernel)
         ybar_used = self.ybar_s if self.rep_standardize_ybar else self.ybar
         return nll_rep_literal(self.x_unique_s, ybar_used, self.ybar_std, self.rep_standardize_ybar, self.r,
-                               self.phi, self.diag_D, self.n, self.p, lLmb, lLmb0, ls2b, lnug)
+                               self.phi, self.diag_D, self.n, self.p, lLmb, lLmb0, ls2b, lnug, kernel=self.kernel)
 
     def loss_and_grad_unconstrained(self, u=None):
         if u is not None:
@@ -509,7 +523,7 @@ class OracleLCGP:
         cinvm = np.zeros((self.q, self.n))
         ths = np.zeros((self.q, self.n, self.n))
         for k in range(self.q):
-            ck = matern32(self.x, self.x, lLmb[k], lLmb0[k], lnug[k])
+            ck = matern32(self.x, self.x, lLmb[k], lLmb0[k], lnug[k], kernel=self.kernel)
             wk, uk = np.linalg.eigh(ck)
             dk = self.diag_D[k]
             ipd = uk @ (np.diag(1.0 / (1.0 + dk * wk)) @ uk.T)
@@ -529,7 +543,7 @@ class OracleLCGP:
         tks = np.zeros((self.q, n, n))
         mks = np.zeros((self.q, n))
         for k in range(self.q):
-            ck = matern32(self.x_unique_s, self.x_unique_s, lLmb[k], lLmb0[k], lnug[k])
+            ck = matern32(self.x_unique_s, self.x_unique_s, lLmb[k], lLmb0[k], lnug[k], kernel=self.kernel)
             b = r * (ybar.T @ (sis * self.phi[:, k]))
             dk = self.diag_D[k]
             cb = ck @ b
@@ -559,7 +573,7 @@ class OracleLCGP:
                 self._aux = self._aux_full()
             for k in range(self.q):
                 c00 = matern32(x0s, x0s, lLmb[k], lLmb0[k], lnug[k], diag_only=True)
-                c0k = matern32(x0s, self.x, lLmb[k], lLmb0[k], lnug[k])
+                c0k = matern32(x0s, self.x, lLmb[k], lLmb0[k], lnug[k], kernel=self.kernel)
                 ghat[k] = c0k @ self._aux['CinvMs'][k]
                 gvar[k] = c00 - np.sum((c0k @ self._aux['Ths'][k]) ** 2, axis=1)
             self.ghat, self.gvar = ghat, gvar
@@ -581,7 +595,7 @@ class OracleLCGP:
             self._aux = self._aux_rep()
         for k in range(self.q):
             c00 = matern32(x0s, x0s, lLmb[k], lLmb0[k], lnug[k], diag_only=True)
-            c0k = matern32(x0s, self.x_unique_s, lLmb[k], lLmb0[k], lnug[k])
+            c0k = matern32(x0s, self.x_unique_s, lLmb[k], lLmb0[k], lnug[k], kernel=self.kernel)
             ghat[k] = c0k @ self._aux['CinvMs'][k]
             gvar[k] = c00 - np.sum((c0k @ self._aux['Tks'][k]) * c0k, axis=1)
         self.ghat, self.gvar = ghat, gvar

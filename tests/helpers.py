@@ -11,7 +11,8 @@ from oracle import lcgp_oracle as orc
 class OracleEngine:
     device = None
 
-    def __init__(self, x, Y, sr=None, q_local=1, dtype='float64', device=None, comp_ids=None, q_total=None):
+    def __init__(self, x, Y, sr=None, q_local=1, dtype='float64', device=None, comp_ids=None, q_total=None, kernel='matern32'):
+        self.kernel = kernel
         self.comp_ids = list(range(q_local)) if comp_ids is None else list(comp_ids)
         self.q_total = q_local if q_total is None else q_total
         self.x = np.asarray(x, np.float64)
@@ -29,8 +30,8 @@ class OracleEngine:
         for i, th in enumerate(np.asarray(theta_rows, np.float64)):
             ell, scale, nug, D, psi = th[:d], th[d], th[d + 1], th[d + 2], th[d + 3:]
             b = self.Y.T @ psi
-            low, c0, s_all, hl, z = orc._chol_component(self.x, ell, scale, nug, D, b, self.sr)
-            ge, gs, gn = orc._kernel_param_grads(low, c0, s_all, z, D, ell, scale, nug, self.sr)
+            low, c0, s_all, hl, z = orc._chol_component(self.x, ell, scale, nug, D, b, self.sr, kernel=self.kernel)
+            ge, gs, gn = orc._kernel_param_grads(low, c0, s_all, z, D, ell, scale, nug, self.sr, kernel=self.kernel)
             out[i, 0], out[i, 1], out[i, 2] = hl, b @ (b - z), 0.0
             out[i, 3:3 + d], out[i, 3 + d], out[i, 4 + d] = ge, gs, gn
             out[i, 5 + d:] = self.Y @ (b - z)
@@ -76,7 +77,7 @@ class OracleEngine:
             a = x0s / ell
             bb = self.x / ell
             S = np.abs(a[:, None, :] - bb[None, :, :])
-            c0 = np.prod(1 + S, axis=2) * np.exp(-S.sum(axis=2))
+            c0 = np.exp(-0.5 * (S * S).sum(axis=2)) if self.kernel == 'se' else np.prod(1 + S, axis=2) * np.exp(-S.sum(axis=2))
             nt = nug / (1 + nug)
             c = scale * ((1 - nt) * c0 + (nt * np.eye(n0) if same else 0.0)) * sr[None, :]
             gh[i] = c @ z
@@ -113,9 +114,9 @@ def patch_engine(model):
             sr = _np.sqrt(model.r.numpy().astype(float))
             yb = (model.ybar_s if model.rep_standardize_ybar else model.ybar).numpy()
             return OracleEngine(model.x_unique_s.numpy(), yb * sr[None, :], sr, len(model._local_ks),
-                                comp_ids=model._local_ks, q_total=model.q)
+                                comp_ids=model._local_ks, q_total=model.q, kernel=model.kernel)
         return OracleEngine(model.x.numpy(), model.y.numpy(), None, len(model._local_ks),
-                            comp_ids=model._local_ks, q_total=model.q)
+                            comp_ids=model._local_ks, q_total=model.q, kernel=model.kernel)
 
     model._make_engine = _make
     return model

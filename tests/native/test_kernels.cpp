@@ -164,7 +164,7 @@ static void run_case(int n, int d, int p, int q, bool rep, unsigned seed) {
         return vec(h.begin(), h.end());
     };
 
-    LCHK(lcgp_kernel_build(nullptr, dtype, n, d, p, q, dx, srp, dtheta, ws));
+    LCHK(lcgp_kernel_build(nullptr, dtype, LCGP_KERNEL_MATERN32, n, d, p, q, dx, srp, dtheta, ws));
     HIPCHK(hipDeviceSynchronize());
     std::vector<vec> Aall(q), C0all(q);
     std::vector<std::vector<vec>> Sall(q);
@@ -231,7 +231,7 @@ static void run_case(int n, int d, int p, int q, bool rep, unsigned seed) {
 
     // whole path
     HIPCHK(hipMemset(ws, 0xff, wsb));
-    LCHK(lcgp_nll_grad(nullptr, dtype, n, d, p, q, dx, dY, srp, dtheta, ws, dout, nullptr, nullptr));
+    LCHK(lcgp_nll_grad(nullptr, dtype, LCGP_KERNEL_MATERN32, n, d, p, q, dx, dY, srp, dtheta, ws, dout, nullptr, nullptr));
     HIPCHK(hipDeviceSynchronize());
     vec hout((size_t)q * ow);
     HIPCHK(hipMemcpy(hout.data(), dout, hout.size() * 8, hipMemcpyDeviceToHost));
@@ -294,7 +294,7 @@ static void run_case(int n, int d, int p, int q, bool rep, unsigned seed) {
         LCHK(lcgp_plan_info(plan.data(), &nl, &inv));
         HIPCHK(hipMemset(ws, 0xff, wsb));
         HIPCHK(hipMemset(dout, 0, (size_t)q * ow * 8));
-        LCHK(lcgp_nll_grad(nullptr, dtype, n, d, p, q, dx, dY, srp, dtheta, ws, dout, nullptr, plan.data()));
+        LCHK(lcgp_nll_grad(nullptr, dtype, LCGP_KERNEL_MATERN32, n, d, p, q, dx, dY, srp, dtheta, ws, dout, nullptr, plan.data()));
         HIPCHK(hipDeviceSynchronize());
         vec hout2((size_t)q * ow);
         HIPCHK(hipMemcpy(hout2.data(), dout, hout2.size() * 8, hipMemcpyDeviceToHost));
@@ -326,7 +326,7 @@ static void run_case(int n, int d, int p, int q, bool rep, unsigned seed) {
         HIPCHK(hipMalloc(&dgh, (size_t)q * n0 * 8));
         HIPCHK(hipMalloc(&dgv, (size_t)q * n0 * 8));
         HIPCHK(hipMemcpy(dx0, x0s.data(), x0s.size() * sizeof(T), hipMemcpyHostToDevice));
-        LCHK(lcgp_predict(nullptr, dtype, n, d, p, q, dx, srp, dtheta, ws, n0, dx0, 0, dscr, dgh, dgv, 0));
+        LCHK(lcgp_predict(nullptr, dtype, LCGP_KERNEL_MATERN32, n, d, p, q, dx, srp, dtheta, ws, n0, dx0, 0, dscr, dgh, dgv, 0));
         HIPCHK(hipDeviceSynchronize());
         vec gh((size_t)q * n0), gv((size_t)q * n0), ghr((size_t)q * n0), gvr((size_t)q * n0);
         HIPCHK(hipMemcpy(gh.data(), dgh, gh.size() * 8, hipMemcpyDeviceToHost));

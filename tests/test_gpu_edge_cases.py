@@ -166,7 +166,7 @@ def test_c_abi_argument_checks():
     assert lib.lcgp_workspace_bytes(2, 10, 2, 2, 1, C.byref(nbytes)) < 0          # bad dtype
     assert lib.lcgp_workspace_bytes(0, 0, 2, 2, 1, C.byref(nbytes)) < 0           # n < 1
     assert lib.lcgp_workspace_bytes(0, 10, 2, 2, 0, C.byref(nbytes)) < 0          # q_local < 1
-    assert lib.lcgp_nll_grad(None, 0, 10, 2, 2, 1, None, None, None, None, None, None, None, None) < 0
+    assert lib.lcgp_nll_grad(None, 0, 0, 10, 2, 2, 1, None, None, None, None, None, None, None, None) < 0
     assert b'NULL' in lib.lcgp_last_error()
     bad = _hip.default_sched()
     bad.outer_blocks = 65

@@ -48,8 +48,9 @@ def test_percentile_nearest_indices():
         assert orc.percentile50_nearest(row, axis=1)[0, 0] == float(idx)
 
 
-def test_eigh_form_equals_cholesky_form():
-    m = _full_model(diag_error_structure=[2, 1, 1])
+@pytest.mark.parametrize("kernel", ["matern32", "se"])
+def test_eigh_form_equals_cholesky_form(kernel):
+    m = _full_model(diag_error_structure=[2, 1, 1], kernel=kernel)
     for u in synth.param_points(11, m.get_unconstrained()):
         m.set_unconstrained(u)
         a, b = m.loss_reference_form(), m.loss()
@@ -84,10 +85,14 @@ def test_full_equals_n_times_rep_when_no_replicates():
         assert abs(a - b) <= 1e-9 * max(1.0, abs(a)), (i, a, b)
 
 
-@pytest.mark.parametrize("kind", ["full", "full_grouped", "rep_std", "rep_raw"])
+@pytest.mark.parametrize("kind", ["full", "full_grouped", "rep_std", "rep_raw", "full_se", "rep_se"])
 def test_closed_form_gradient_matches_finite_differences(kind):
     if kind == "full":
         m = _full_model()
+    elif kind == "full_se":         # the squared-exponential extension: no reference, identities are its only check
+        m = _full_model(kernel='se')
+    elif kind == "rep_se":
+        m = _rep_model(kernel='se')
     elif kind == "full_grouped":
         m = _full_model(diag_error_structure=[1, 3], robust_mean=False)
     elif kind == "rep_std":
@@ -101,10 +106,11 @@ def test_closed_form_gradient_matches_finite_differences(kind):
         np.testing.assert_allclose(g, fd, rtol=2e-5, atol=2e-6 * max(1.0, np.max(np.abs(fd))))
 
 
-def test_gradient_matches_torch_autograd_of_literal_form():
+@pytest.mark.parametrize("kernel", ["matern32", "se"])
+def test_gradient_matches_torch_autograd_of_literal_form(kernel):
     """Independent check: autograd through the eigh-form objective (what TF's tape does)."""
     torch = pytest.importorskip("torch")
-    m = _full_model(n=40)
+    m = _full_model(n=40, kernel=kernel)
     u = synth.param_points(15, m.get_unconstrained())[1]
     _, g = m.loss_and_grad_unconstrained(u)
     lLmb, lLmb0, ls2b, lnug = m.get_param()
@@ -119,7 +125,7 @@ def test_gradient_matches_torch_autograd_of_literal_form():
     for k in range(m.q):
         a = x / t['l'][k]
         S = (a[:, None, :] - a[None, :, :]).abs()
-        c0 = torch.prod(1 + S, dim=2) * torch.exp(-S.sum(dim=2))
+        c0 = torch.exp(-0.5 * (S * S).sum(dim=2)) if kernel == 'se' else torch.prod(1 + S, dim=2) * torch.exp(-S.sum(dim=2))
         nt = t['v'][k] / (1 + t['v'][k])
         ck = t['s'][k] * ((1 - nt) * c0 + nt * torch.eye(n, dtype=torch.float64))
         wk, uk = torch.linalg.eigh(ck)
@@ -156,3 +162,19 @@ def test_predict_rep_simplified_identities():
         np.testing.assert_allclose(aux['CinvMs'][k], sr * z, rtol=1e-7, atol=1e-9)
         np.testing.assert_allclose(aux['mks'][k], (beta - z) / (m.diag_D[k] * sr), rtol=1e-7, atol=1e-9)
         np.testing.assert_allclose(aux['Tks'][k], m.diag_D[k] * ainv * sr[:, None] * sr[None, :], rtol=1e-5, atol=1e-7)
+
+
+def test_se_kernel_definition_and_rep_literal_form():
+    """the extension's kernel: exp(-1/2 sum ((x - x') / ell)^2) with Matern32's nugget / scale structure; its replicated
+    objective equals the step-by-step form as the Matern one does"""
+    rng = np.random.default_rng(3)
+    a, b = rng.uniform(size=(7, 3)), rng.uniform(size=(5, 3))
+    ell = np.array([0.6, 1.1, 0.3])
+    want = 1.7 * (1 - 0.02 / 1.02) * np.exp(-0.5 * (((a[:, None, :] - b[None, :, :]) / ell) ** 2).sum(axis=2))
+    np.testing.assert_allclose(orc.matern32(a, b, ell, 1.7, 0.02, kernel='se'), want, rtol=1e-14)
+    same = orc.matern32(a, a, ell, 1.7, 0.02, kernel='se')
+    np.testing.assert_allclose(np.diag(same), 1.7, rtol=1e-14)          # (1 - nt) + nt on the diagonal
+    m = _rep_model(kernel='se')
+    for u in synth.param_points(12, m.get_unconstrained()):
+        m.set_unconstrained(u)
+        assert abs(m.loss_reference_form() - m.loss()) <= 1e-10 * max(1.0, abs(m.loss()))

@@ -49,14 +49,14 @@ int main() {
         std::vector<double> o1((size_t)q * ow), o2((size_t)q * ow);
         for (int rep = 0; rep < 3; ++rep) {
             CK(hipEventRecord(e0, st));
-            if (lcgp_nll_grad(st, 0, n, d, p, q, dx, dY, nullptr, dth, ws, dout, nullptr, nullptr)) { printf("nll_grad failed: %s\n", lcgp_last_error()); return 1; }
+            if (lcgp_nll_grad(st, 0, 0, n, d, p, q, dx, dY, nullptr, dth, ws, dout, nullptr, nullptr)) { printf("nll_grad failed: %s\n", lcgp_last_error()); return 1; }
             CK(hipEventRecord(e1, st)); CK(hipEventSynchronize(e1)); CK(hipEventElapsedTime(&ms, e0, e1));
             printf("q=%d plain  nll_grad %.3f ms\n", q, ms);
         }
         CK(hipMemcpy(o1.data(), dout, o1.size() * 8, hipMemcpyDeviceToHost));
         hipGraph_t gr; hipGraphExec_t ge;
         CK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
-        if (lcgp_nll_grad(st, 0, n, d, p, q, dx, dY, nullptr, dth, ws, dout, nullptr, nullptr)) { printf("capture failed: %s\n", lcgp_last_error()); return 1; }
+        if (lcgp_nll_grad(st, 0, 0, n, d, p, q, dx, dY, nullptr, dth, ws, dout, nullptr, nullptr)) { printf("capture failed: %s\n", lcgp_last_error()); return 1; }
         CK(hipStreamEndCapture(st, &gr));
         size_t nn = 0; CK(hipGraphGetNodes(gr, nullptr, &nn));
         CK(hipGraphInstantiate(&ge, gr, nullptr, nullptr, 0));

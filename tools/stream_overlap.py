@@ -60,7 +60,7 @@ def main():
 
     def run_a():
         st = C.c_void_p(s1.cuda_stream)
-        _hip.check(lib.lcgp_kernel_build(st, ea.dtype, ea.n, ea.d, ea.p, ea.q_local, ea._p(ea.x), ea._p(ea.sr),
+        _hip.check(lib.lcgp_kernel_build(st, ea.dtype, ea.kernel_id, ea.n, ea.d, ea.p, ea.q_local, ea._p(ea.x), ea._p(ea.sr),
                                          ea._p(ea.theta_dev), ea._p(ea.workspace)), 'build')
         _hip.check(lib.lcgp_potrf_logdet(st, ea.dtype, ea.n, ea.d, ea.p, ea.q_local, ea._p(ea.workspace),
                                          C.c_void_p(ld.data_ptr()), C.c_void_p(info.data_ptr()), ea._sched(), ea.plan(False)), 'potrf')
