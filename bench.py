@@ -156,6 +156,7 @@ def cpu_baseline(m, budget_s=12.0, repeats=5):
     ns = n
     while ns > probe_n and t_probe * (ns / probe_n) ** 3 > budget_s:
         ns //= 2
+    repeats = max(1, int(repeats))
     t_eighs = [eigh(ns)[0] for _ in range(repeats)]
     chols = [chol(ns) for _ in range(repeats)]
     t_chols = [c[0] for c in chols]

@@ -136,13 +136,17 @@ int lcgp_potri(void* stream, int dtype, int n, int d, int p, int q_local, void* 
 int lcgp_trtri(void* stream, int dtype, int n, int d, int p, int q_local, void* workspace, const lcgp_sched* sched);
 int lcgp_lauum(void* stream, int dtype, int n, int d, int p, int q_local, void* workspace, const lcgp_sched* sched);
 
-/* Measurement support (no counterpart in the reference): the first workgroup of the one-launch A^-1 = W^T W (lcgp_lauum, and
- * the same launch inside lcgp_nll_grad, on 128x128 tiles) stamps its K loop -- the longest of the launch -- with the
- * shader-clock counter and with the 100 MHz real-time counter; this copies the two durations of the LAST such launch to
- * `out` (device, 2 x 64 bit: shader cycles, 10 ns ticks) and CLEARS them: zeros mean that no stamped launch has run since
- * the last call (the 64x64-tile form of the launch, used for small problems and single components, does not stamp; a fresh
- * workspace holds garbage until the first call).  cycles / ticks x 100 = the clock in MHz the chip held while the fp64 MFMA
- * pipe was loaded, measured in the un-profiled path (bench.py: roofline.clock_mhz). */
+/* Measurement support (no counterpart in the reference): wave 0 of the first workgroup of
+ *   - the launch that forms A^-1 = W^T W (lcgp_lauum, and the same launch inside lcgp_nll_grad), in either tile size, and
+ *   - the first (widest) trailing update of every factorisation -- which is what remains to be stamped in the configurations
+ *     whose A^-1 is accumulated behind the factorisation (few components per rank, small n: lcgp_sched.progressive_*)
+ * stamps its K loop with the shader-clock counter and with the 100 MHz real-time counter; this copies the two durations of
+ * the LAST stamped launch to `out` (device, 2 x 64 bit: shader cycles, 10 ns ticks) and CLEARS them: zeros mean that no
+ * stamped launch has run since the last call (a fresh workspace holds garbage until the first call).
+ * cycles / ticks x 100 = the clock in MHz the chip held while the fp64 MFMA pipe was loaded, measured in the un-profiled
+ * path (bench.py: roofline.clock_mhz).  The window is approximate -- the stamps are scalar instructions the compiler may
+ * move a few instructions into the tile's prologue / epilogue -- and short in small configurations (tens of microseconds:
+ * the ratio then carries the 10 ns granularity of the real-time counter, ~0.1 %). */
 int lcgp_lauum_clock(void* stream, int dtype, int n, int d, int p, int q_local, const void* workspace,
                      unsigned long long* out /*device, 2 words*/);
 

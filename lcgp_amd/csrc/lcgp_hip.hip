@@ -1059,10 +1059,14 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, const int lin /*blo
 
     constexpr int SPT = TM / KT;   // stages per k tile
     const int nst = nkt * SPT;
-    // (measurement support: the first block of the one-launch A^-1 = W^T W has the longest K loop of the launch; wave 0 stamps it
-    // with the shader-clock counter and the 100 MHz real-time counter, both scalar: the ratio is the clock the chip held)
+    // (measurement support: where the host passes the two clock words -- the launch that forms A^-1 = W^T W, in either tile
+    // size, and the first wide trailing update of the factorisation, which is what is left to stamp where A^-1 is accumulated
+    // behind the chain -- wave 0 of the first block (the longest K loop of such a launch) stamps its K loop and epilogue
+    // with the shader-clock counter and the 100 MHz real-time counter, both scalar: the ratio is the clock the chip held.
+    // The window is approximate: the stamps are scalar instructions the compiler may schedule a few instructions into the
+    // prologue / epilogue either way)
     unsigned long long clk0 = 0, rt0 = 0;
-    if constexpr (OP == OP_LAUUM && TM == 128) {
+    if constexpr (OP == OP_LAUUM || OP == OP_SYRK) {
         if (g.clk && lin == 0 && wave == 0) { clk0 = __builtin_amdgcn_s_memtime(); rt0 = __builtin_amdgcn_s_memrealtime(); }
     }
     // The LAST k tile of the triangular products holds a triangular TM x TM block of W (LAUUM: W[r,r] as A, and as B too
@@ -1275,7 +1279,7 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, const int lin /*blo
                     BufIo<T>::store((T)v, crs, dvoff, dsoff);
                 }
             }
-    if constexpr (OP == OP_LAUUM && TM == 128) {
+    if constexpr (OP == OP_LAUUM || OP == OP_SYRK) {
         if (g.clk && lin == 0 && wave == 0) {
             const unsigned long long c1 = __builtin_amdgcn_s_memtime() - clk0, r1 = __builtin_amdgcn_s_memrealtime() - rt0;
             if (lane == 0) { g.clk[0] = c1; g.clk[1] = r1; }
@@ -2486,12 +2490,14 @@ int launch_fill(hipStream_t st, const FillSet& fs) {
 
 // trailing update with the panel [J, pe) of the tile columns [c_lo, c_hi) (64-block units, all rows below)
 template <typename T>
-int potrf_trailing(hipStream_t st, const Ws& w, int J, int pe, int c_lo, int c_hi, bool tiles128, bool with_leaf) {
+int potrf_trailing(hipStream_t st, const Ws& w, int J, int pe, int c_lo, int c_hi, bool tiles128, bool with_leaf,
+                   unsigned long long* clk = nullptr) {
     if (c_lo >= c_hi) return 0;
     T* M = (T*)(w.base + w.off_M);
     GemmArgs g;
     g.sA = g.sB = g.sC = w.mat; g.ldA = g.ldB = g.ldC = w.npad;
     g.A = M; g.B = M; g.C = M;
+    g.clk = clk;
     // 128x128 tiles when the panel boundaries are 128-aligned AND the launch has enough of them to fill the chip (the
     // plan decides); a launch with few tiles is bounded by the duration of one tile, which is 4x shorter on 64x64 tiles
     if (tiles128) {
@@ -2618,6 +2624,7 @@ int do_potrf(hipStream_t st, const Ws& w, const lcgp_sched& sc, bool stats_zeroe
     if (inverse_done) *inverse_done = h->inverse_done;
     const lcgp_fill::Launch* launches = (const lcgp_fill::Launch*)((const char*)plan_host + h->off_launch);
     const int nlaunch = h->nlaunch;
+    bool first_trail = true;
     for (int li = 0; li < nlaunch; ++li) {
         const lcgp_fill::Launch& l = launches[li];
         FillSet fs = l.fs;
@@ -2648,7 +2655,11 @@ int do_potrf(hipStream_t st, const Ws& w, const lcgp_sched& sc, bool stats_zeroe
                 break;
             }
             case lcgp_fill::L_TRAIL:
-                rc = potrf_trailing<T>(st, w, l.J, l.pe, l.c_lo, l.c_hi, l.tiles128 != 0, l.with_leaf != 0);
+                // (the first trailing update -- the widest -- leaves the clock words of lcgp_lauum_clock; a later A^-1 launch
+                // overwrites them)
+                rc = potrf_trailing<T>(st, w, l.J, l.pe, l.c_lo, l.c_hi, l.tiles128 != 0, l.with_leaf != 0,
+                                       first_trail ? (unsigned long long*)(w.base + w.off_clock) : nullptr);
+                first_trail = false;
                 break;
             default:
                 rc = launch_fill<T>(st, fs);
@@ -2707,6 +2718,7 @@ int do_lauum(hipStream_t st, const Ws& w, const lcgp_sched& sc, bool* z_partials
     g.sA = g.sB = g.sC = w.mat; g.ldA = g.ldB = g.ldC = w.npad; g.p0 = g.p1 = g.p2 = g.p3 = 0;
     g.A = (T*)(w.base + w.off_W); g.B = g.A; g.C = (T*)(w.base + w.off_V);
     if (z_partials) *z_partials = false;
+    g.clk = (unsigned long long*)(w.base + w.off_clock);      // (either tile size stamps its first block: lcgp_lauum_clock)
     if (use_small_tiles(w, sc.lauum_small_tiles)) {
         g.nb = w.nb;
         return launch_gemm<T, OP_LAUUM, 64>(st, g, w.nb * (w.nb + 1) / 2, w.q);
@@ -2717,7 +2729,6 @@ int do_lauum(hipStream_t st, const Ws& w, const lcgp_sched& sc, bool* z_partials
     // workspace may then be stale and the partials are never read): one launch shape to measure and to maintain
     g.bvec = w.base + w.off_b;
     g.part = (double*)(w.base + w.off_part);
-    g.clk = (unsigned long long*)(w.base + w.off_clock);
     if (z_partials) *z_partials = true;
     return launch_gemm<T, OP_LAUUM, 128>(st, g, nb2 * (nb2 + 1) / 2, w.q);
 }

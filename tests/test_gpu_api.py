@@ -243,6 +243,27 @@ def test_the_inverse_launch_reports_the_clock_it_ran_at():
     _hip.check(eng.lib.lcgp_lauum_clock(eng._stream(), eng.dtype, eng.n, eng.d, eng.p, eng.q_local, eng._p(eng.workspace),
                                         C.c_void_p(clk.data_ptr())), 'lcgp_lauum_clock')
     assert [int(v) for v in clk.cpu()] == [0, 0]
+    # the 64x64-tile form of the launch (small problems, single components) stamps its first block too, and so does the first
+    # trailing update of a factorisation (what is left to read where A^-1 is accumulated behind the chain)
+    big = 10 ** 9
+    for which in ('lauum64', 'potrf'):
+        if which == 'lauum64':
+            sc.lauum_small_tiles = big
+            _hip.check(eng.lib.lcgp_lauum(eng._stream(), eng.dtype, eng.n, eng.d, eng.p, eng.q_local, eng._p(eng.workspace),
+                                          C.byref(sc)), 'lcgp_lauum')
+        else:
+            m.loss()                            # kernel build + factorisation + ... (the last stamped launch: A^-1)
+            _hip.check(eng.lib.lcgp_lauum_clock(eng._stream(), eng.dtype, eng.n, eng.d, eng.p, eng.q_local, eng._p(eng.workspace),
+                                                C.c_void_p(clk.data_ptr())), 'lcgp_lauum_clock')
+            _hip.check(eng.lib.lcgp_kernel_build(eng._stream(), eng.dtype, eng.kernel_id, eng.n, eng.d, eng.p, eng.q_local,
+                                                 eng._p(eng.x), eng._p(eng.sr), eng._p(eng.theta_dev), eng._p(eng.workspace)),
+                       'lcgp_kernel_build')
+            _hip.check(eng.lib.lcgp_potrf_logdet(eng._stream(), eng.dtype, eng.n, eng.d, eng.p, eng.q_local, eng._p(eng.workspace),
+                                                 None, None, None, None), 'lcgp_potrf_logdet')
+        _hip.check(eng.lib.lcgp_lauum_clock(eng._stream(), eng.dtype, eng.n, eng.d, eng.p, eng.q_local, eng._p(eng.workspace),
+                                            C.c_void_p(clk.data_ptr())), 'lcgp_lauum_clock')
+        cyc, ticks = (int(v) for v in clk.cpu())
+        assert ticks > 0 and 500.0 < 100.0 * cyc / ticks < 3000.0, (which, cyc, ticks)
 
 
 def test_bench_line_keeps_its_contract():
