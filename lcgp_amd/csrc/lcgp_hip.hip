@@ -197,6 +197,16 @@ __device__ __forceinline__ double exp_nonpos(double x) {
 // float32 (no reference precision to match): v_exp_f32 on x log2(e); the absolute error stays below 1e-7
 __device__ __forceinline__ float exp_nonpos(float x) { return __expf(x); }
 
+// C0 = prod_j (1 + S_j) exp(-sum_j S_j): where the exponent is below the smallest normal number's logarithm the value is
+// zero for every purpose of the path -- but the POLYNOMIAL there may have overflowed (lengthscales at their lower SoftClip
+// bound 1e-6: S_j ~ 1e6, ten dimensions: 1e60, beyond float32's range), and inf x 0 is a NaN that takes the whole
+// factorisation with it: this is what ended float32 fits of configs[3] (profiles/r06_fp32_breakdown.txt: status word 2 at
+// lambda_max(A) ~ 5 .. 130, i.e. nothing to do with conditioning).  Above the threshold prod (1 + S_j) <= exp(sum S_j) is
+// finite.  The matrices stay identical wherever they were finite before.
+template <typename T> __device__ __forceinline__ constexpr T exp_floor();
+template <> __device__ __forceinline__ constexpr double exp_floor<double>() { return -708.0; }
+template <> __device__ __forceinline__ constexpr float exp_floor<float>() { return -87.0f; }
+
 // ---------------------------------------------------------------------------------------------------
 // K1: kernel build.   A_ij = delta_ij + D sr_i sr_j s ((1 - nt) C0_ij + nt delta_ij)
 //   C0 = prod_j (1 + S_j) exp(-sum_j S_j),  S_j = |x_i,j/ell_j - x_i',j/ell_j|      (covmat.py:35-53)
@@ -311,7 +321,7 @@ __global__ __launch_bounds__(256) void build_kernel(T* __restrict__ M, size_t ma
         for (int b = 0; b < 4; ++b) {
             const int gj = c * TS + colof(b);
             if (gi < n && gj < n) {
-                const T c0 = poly[a][b] * exp_nonpos(ssum[a][b]);
+                const T c0 = ssum[a][b] < exp_floor<T>() ? (T)0 : poly[a][b] * exp_nonpos(ssum[a][b]);
                 const T ss = srr[i0 + a] * src[colof(b)];
                 v[b] = ss * c_off * c0;
                 if (gi == gj) v[b] += (T)1 + (c_diag - (T)1) * ss;
@@ -395,7 +405,7 @@ __global__ __launch_bounds__(256) void cross_kernel(T* __restrict__ out, int ldo
         if (gi >= n1pad || gj >= n2pad) continue;
         double v = 0.0;
         if (gi < n1 && gj < n2) {
-            double c0 = poly[m] * exp_nonpos(ssum[m]);
+            double c0 = ssum[m] < exp_floor<double>() ? 0.0 : poly[m] * exp_nonpos(ssum[m]);
             double dl = (same && gi + (same - 1) == gj) ? 1.0 : 0.0;   // same = 1 + row offset of x1 within x2
             v = scale * ((1.0 - nt) * c0 + nt * dl) * cs[j];
         }
@@ -2043,6 +2053,7 @@ __global__ __launch_bounds__(256) void grad_kernel(const T* __restrict__ V, size
                     ssum = fma(-0.5 * s, s, ssum);
                 }
             }
+            if (ssum < exp_floor<double>()) continue;      // C0 = 0 here (and its polynomial may be inf): no contribution
             const double ex = exp_nonpos(ssum);
             const double ge = G * ex;
             if constexpr (CZ) {
@@ -2198,7 +2209,9 @@ __global__ __launch_bounds__(256) void grad_kernel_wide(const T* __restrict__ V,
             if (gi < n && gj < n && gj <= gi) {
                 const double wgt = gi == gj ? 1.0 : 2.0;
                 const double G = wgt * srr[i] * src[j] * (0.5 * D * (double)avs[m][h] - 0.5 * zr[i] * zc[j]);
-                const double ex = exp_nonpos(geT[2 * m + h]);
+                const bool zero = geT[2 * m + h] < exp_floor<double>();       // C0 = 0 (its polynomial may be inf)
+                if (zero) prodT[2 * m + h] = 0.0;
+                const double ex = zero ? 0.0 : exp_nonpos(geT[2 * m + h]);
                 ge = G * ex;
                 a_scale = fma(ge, prodT[2 * m + h], a_scale);
                 if (gi == gj) a_nug += G;

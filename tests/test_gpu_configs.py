@@ -180,7 +180,9 @@ def test_cfg4_float32_quadratic_form_without_cancellation_and_fit():
     of the 4096-point prefix is within 1e-5 relative of the float64 oracle (round 2: 1.6e-4 with the difference formed
     directly).  (ii) fit() in float32 ends where the float64 fit ends (final losses, both re-evaluated in float64,
     within 1e-3 relative): points at which the float32 factorisation breaks down along a line search are evaluated in
-    float64 instead of being reported as artificial values, and the run is restarted while it still gains."""
+    float64 instead of being reported as artificial values, the run is restarted while it still gains, and a float32 run
+    whose line search ends in the noise floor (this prefix: a long flat valley, 730 float64 evaluations) is carried on in
+    float64 (`opt_result.restarts[-1]['float64']`)."""
     x, y, cfg = synth.make_config(4)
     x, y = x[:4096], y[:, :4096]
     m32 = LCGP(y=y, x=x, q=cfg['q'], dtype='float32')

@@ -111,6 +111,28 @@ def test_parameters_near_the_softclip_bounds():
     _same(m, o, u)
 
 
+def test_float32_survives_collapsed_lengthscales():
+    """Ten input dimensions with every lengthscale at its lower SoftClip bound (1e-6): the polynomial factor of the Matern
+    kernel is ~(1e6)^10, beyond float32's range, and its exponential factor is zero -- inf x 0 used to put NaNs into the
+    float32 matrix (status word 2 at a perfectly conditioned matrix; this is what sent float32 fits of configs[3] to
+    float64: profiles/r06_fp32_breakdown.txt).  Both precisions must evaluate such a point, and agree."""
+    x, y = synth.make_full(323, 300, 10, 4, 2)
+    m64 = LCGP(y=y, x=x, q=2)
+    m32 = LCGP(y=y, x=x, q=2, dtype='float32')
+    m32.float32_fallback = False                     # no float64 repeat: the float32 engine itself has to cope
+    u = m64._get_flat().copy()
+    u[:20] = -40.0                                   # all 2 x 10 lengthscales at the bound
+    v64, g64 = m64.loss_and_grad(u)
+    v32, g32 = m32.loss_and_grad(u)
+    assert np.isfinite(v32) and np.all(np.isfinite(g32))
+    assert abs(v32 - v64) <= 2e-4 * abs(v64)
+    assert np.max(np.abs(g32 - g64)) <= 2e-2 * max(np.max(np.abs(g64)), 1e-300)
+    o = orc.OracleLCGP(y=y, x=x, q=2)
+    o.phi = m64.phi.numpy().copy()
+    vo, go = o.loss_and_grad_unconstrained(u)
+    assert abs(v64 - vo) <= 1e-6 * abs(vo) and np.max(np.abs(g64 - go)) <= 1e-5 * max(np.max(np.abs(go)), 1e-300)
+
+
 @pytest.mark.parametrize('n0', [1, 63, 64, 65, 700])
 def test_predict_sizes(n0):
     x, y = synth.make_full(322, 200, 2, 3, 3)
