@@ -203,6 +203,11 @@ __device__ __forceinline__ float exp_nonpos(float x) { return __expf(x); }
 // factorisation with it: this is what ended float32 fits of configs[3] (profiles/r06_fp32_breakdown.txt: status word 2 at
 // lambda_max(A) ~ 5 .. 130, i.e. nothing to do with conditioning).  Above the threshold prod (1 + S_j) <= exp(sum S_j) is
 // finite.  The matrices stay identical wherever they were finite before.
+// (kernel build / cross covariance: the polynomial is capped instead -- one v_min per element in a kernel bound by VALU issue;
+// prod (1 + S_j) <= exp(sum S_j), so a polynomial beyond the cap meets an exponential that has underflowed to zero long before)
+template <typename T> __device__ __forceinline__ constexpr T poly_cap();
+template <> __device__ __forceinline__ constexpr double poly_cap<double>() { return 1e300; }
+template <> __device__ __forceinline__ constexpr float poly_cap<float>() { return 1e38f; }
 template <typename T> __device__ __forceinline__ constexpr T exp_floor();
 template <> __device__ __forceinline__ constexpr double exp_floor<double>() { return -708.0; }
 template <> __device__ __forceinline__ constexpr float exp_floor<float>() { return -87.0f; }
@@ -321,7 +326,7 @@ __global__ __launch_bounds__(256) void build_kernel(T* __restrict__ M, size_t ma
         for (int b = 0; b < 4; ++b) {
             const int gj = c * TS + colof(b);
             if (gi < n && gj < n) {
-                const T c0 = ssum[a][b] < exp_floor<T>() ? (T)0 : poly[a][b] * exp_nonpos(ssum[a][b]);
+                const T c0 = fmin(poly[a][b], poly_cap<T>()) * exp_nonpos(ssum[a][b]);
                 const T ss = srr[i0 + a] * src[colof(b)];
                 v[b] = ss * c_off * c0;
                 if (gi == gj) v[b] += (T)1 + (c_diag - (T)1) * ss;
@@ -405,7 +410,7 @@ __global__ __launch_bounds__(256) void cross_kernel(T* __restrict__ out, int ldo
         if (gi >= n1pad || gj >= n2pad) continue;
         double v = 0.0;
         if (gi < n1 && gj < n2) {
-            double c0 = ssum[m] < exp_floor<double>() ? 0.0 : poly[m] * exp_nonpos(ssum[m]);
+            double c0 = fmin(poly[m], poly_cap<double>()) * exp_nonpos(ssum[m]);
             double dl = (same && gi + (same - 1) == gj) ? 1.0 : 0.0;   // same = 1 + row offset of x1 within x2
             v = scale * ((1.0 - nt) * c0 + nt * dl) * cs[j];
         }
@@ -825,6 +830,11 @@ __device__ __forceinline__ void vm_wait_set(P (&a)[1], P (&b)[1]) {
     asm volatile("s_waitcnt vmcnt(%2)" : "+v"(a[0]), "+v"(b[0]) : "n"(N) : "memory");
 }
 template <int N, typename P>
+__device__ __forceinline__ void vm_wait_set(P (&a)[4], P (&b)[4]) {
+    asm volatile("s_waitcnt vmcnt(%8)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3])
+                 : "n"(N) : "memory");
+}
+template <int N, typename P>
 __device__ __forceinline__ void vm_wait_set(P (&a)[2], P (&b)[2]) {
     asm volatile("s_waitcnt vmcnt(%4)" : "+v"(a[0]), "+v"(a[1]), "+v"(b[0]), "+v"(b[1]) : "n"(N) : "memory");
 }
@@ -1172,7 +1182,7 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, const int lin /*blo
 #ifdef LCGP_SYRK_COUNTED
         constexpr bool COUNTED = PF == 2 && (NPC == 1 || NPC == 2) && (!PRELOAD_C || F64);
 #else
-        constexpr bool COUNTED = PF == 2 && (NPC == 1 || NPC == 2) && !PRELOAD_C;
+        constexpr bool COUNTED = PF == 2 && (NPC == 1 || NPC == 2 || NPC == 4) && !PRELOAD_C;
 #endif
 #else
         constexpr bool COUNTED = false;
@@ -2053,7 +2063,9 @@ __global__ __launch_bounds__(256) void grad_kernel(const T* __restrict__ V, size
                     ssum = fma(-0.5 * s, s, ssum);
                 }
             }
-            if (ssum < exp_floor<double>()) continue;      // C0 = 0 here (and its polynomial may be inf): no contribution
+            // C0 = 0 where its exponential underflows, and the polynomial beside it may have overflowed (inf x 0): no contribution.
+            // (Only the widest instantiation can get there: (1 + S)^16 stays finite for every S below 1e19.)
+            if constexpr (DD > 16) { if (ssum < exp_floor<double>()) continue; }
             const double ex = exp_nonpos(ssum);
             const double ge = G * ex;
             if constexpr (CZ) {
@@ -2449,7 +2461,12 @@ int do_build(hipStream_t st, const Ws& w, const void* x, const void* sr, const d
 template <typename T, int OP, int TM = TS>
 int launch_gemm(hipStream_t st, const GemmArgs& g, int ntiles, int q) {
     if (ntiles <= 0) return 0;
-    constexpr int NW = TM == 128 ? 8 : 4;
+    // 128x128 tiles: eight waves (32x64 each, 128 registers, four waves per SIMD) for the long products of the inverse; FOUR
+    // waves (64x64 each, 233 registers, two per SIMD, still two workgroups per CU) for the rank-256 update, whose 16-stage
+    // tiles spend relatively more time at their barriers: half as many waves to synchronise, twice the MFMAs between two
+    // barriers, half the fragment reads per MFMA (profiles/r06_syrk_ab.txt: 1294 -> 1242 us per evaluation; the long products
+    // lose on four waves: A^-1 2.79 -> 2.83 ms)
+    constexpr int NW = TM == 128 ? (OP == OP_SYRK ? 4 : 8) : 4;
     GemmArgs h = g;
     h.q = q;
     h.t0 = 0;
