@@ -74,7 +74,7 @@ int lcgp_partial_width(int d, int p, int q_total);
  * TIMES the number of local components. */
 typedef struct lcgp_sched {
     int outer_blocks;       /* width of the outer Cholesky panel in 64-column blocks; 0 = automatic (4 fp64, 8 fp32) */
-    int syrk_small_tiles;   /* a trailing update with fewer 128x128 tiles than this runs on 64x64 tiles (2000) */
+    int syrk_small_tiles;   /* a trailing update with fewer 128x128 tiles than this runs on 64x64 tiles (3000) */
     int trtri_small_tiles;  /* the whole triangular inverse runs on 64x64 tiles below this many 128x128 tiles (4200) */
     int lauum_small_tiles;  /* the same for A^-1 = W^T W (2048) */
     int trtri_level_small;  /* a single level of the triangular inverse below this many 128x128 tiles: 64x64 tiles (600) */
@@ -82,7 +82,7 @@ typedef struct lcgp_sched {
                                diagonal-block launch (248 = one per otherwise idle CU; 0 = none) */
     int fill_step;          /* filler blocks carried by a chain-step launch that ends in a diagonal block (248) */
     int leaf_in_wide;       /* a trailing update of at most this many 64x64 tiles also factors the next panel's first
-                               diagonal block, so that panel's chain starts one launch earlier (1024; 0 = never) */
+                               diagonal block, so that panel's chain starts one launch earlier (2048; 0 = never) */
     int progressive_tiles;  /* lcgp_nll_grad only: with at most this many 128x128 lower tiles x components (few components
                                per rank) L^-1 and A^-1 are formed panel by panel BEHIND the factorisation, as filler tiles
                                of the chain launches, instead of after it (600; 0 = never) */

@@ -2483,13 +2483,14 @@ int launch_gemm(hipStream_t st, const GemmArgs& g, int ntiles, int q) {
 inline lcgp_sched default_sched() {
     lcgp_sched s;
     s.outer_blocks = 0;            // 0 = automatic: 4 (fp64) / 8 (fp32) 64-blocks per outer Cholesky panel
-    s.syrk_small_tiles = 2000;     // below this many 128x128 tiles (x components) a trailing update runs on 64x64 tiles
+    s.syrk_small_tiles = 3000;     // below this many 128x128 tiles (x components) a trailing update runs on 64x64 tiles (2000 until
+                                   // round 6: with two prefetch stages and the row image the 64-tile update caught up with the 128-tile one)
     s.trtri_small_tiles = 4200;    // the same switch for the whole triangular inverse ...
     s.lauum_small_tiles = 2048;    // ... and for A^-1 = W^T W
     s.trtri_level_small = 600;     // a single level of the triangular inverse below this many 128x128 tiles: 64x64 tiles
     s.fill_leaf = 248;             // filler blocks (128x64 tiles) carried by a diagonal-block launch
     s.fill_step = 248;             // ... and by a chain-step launch that ends in a diagonal block
-    s.leaf_in_wide = 1024;         // a trailing update of at most this many 64x64 tiles also factors the next diagonal block
+    s.leaf_in_wide = 2048;         // a trailing update of at most this many 64x64 tiles also factors the next diagonal block
     s.progressive_tiles = 600;     // L^-1 and A^-1 formed behind the chain up to this many 128x128 lower tiles x components
                                    // (n = 4096: one component per rank; measured 2.72 -> 2.55 ms there, slower from two on)
     s.progressive_far = 1;         // ... with the far columns of the trailing updates still riding on the chain

@@ -23,7 +23,7 @@ def dump_plan(tmp_path_factory):
     subprocess.run(['g++', '-std=c++17', '-O1', '-I', os.path.join(ROOT, 'lcgp_amd', 'csrc'), '-o', exe,
                     os.path.join(ROOT, 'tests', 'native', 'dump_plan.cpp')], check=True)
 
-    def run(nb, q, ob, syrk_small=2000, fill_leaf=248, fill_step=248, leaf_in_wide=1024, progressive=1, far_rides=1, with_dupd=1):
+    def run(nb, q, ob, syrk_small=3000, fill_leaf=248, fill_step=248, leaf_in_wide=2048, progressive=1, far_rides=1, with_dupd=1):
         out = subprocess.run([exe] + [str(v) for v in (nb, q, ob, syrk_small, fill_leaf, fill_step, leaf_in_wide, progressive,
                                                        far_rides, with_dupd)],
                              check=True, capture_output=True, text=True).stdout
