@@ -994,9 +994,42 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g, const int lin /*blo
     if constexpr (OP == OP_SYRK) {
         // M[r, c] -= sum_{kt in [p0, p1)} M[r, kt] M[c, kt]^T over the tiles c in [p2, p3), r in [c, nb)
         // (p3 == nb: the whole trailing triangle; p3 < nb: the rest of the current panel), column-major
-        int t = bid + g.t0, c = g.p2;
-        while (t >= g.nb - c) { t -= g.nb - c; ++c; }
-        const int r = c + t;
+#ifndef LCGP_SYRK_BAND
+#define LCGP_SYRK_BAND 8
+#endif
+        int t = bid + g.t0, c = g.p2, r;
+        if constexpr (LCGP_SYRK_BAND == 0) {
+            while (t >= g.nb - c) { t -= g.nb - c; ++c; }
+            r = c + t;
+        } else {
+            // Band-major: the rows p2 + i in bands of SB; inside a band column by column.  The workgroups resident on an XCD at
+            // one time (with eight components the component IS the XCD) then cover SB row tiles x a dozen column tiles instead
+            // of ~100 row tiles of one column: their operand panels (SB + a dozen of them) stay in the XCD's 4 MB L2, where the
+            // column-major order re-fetched a row panel per tile (profiles/r06_hbm_traffic_per_kernel.txt: 7.2 GB per
+            // evaluation through the fabric for 1.07 GB of matrix).  Same tiles, same arithmetic per tile.
+            constexpr int SB = LCGP_SYRK_BAND;
+            int i0 = 0;                                   // first row of the band, relative to p2
+            for (;;) {
+                // tiles of the band [i0, i0 + SB): row p2 + i holds the columns p2 .. min(p2 + i, p3 - 1)
+                const int rows = g.nb - g.p2 - i0 < SB ? g.nb - g.p2 - i0 : SB;
+                int cnt = 0;
+                for (int i = i0; i < i0 + rows; ++i) cnt += (i < g.p3 - g.p2 ? i : g.p3 - g.p2 - 1) + 1;
+                if (t < cnt) break;
+                t -= cnt;
+                i0 += SB;
+            }
+            const int rows = g.nb - g.p2 - i0 < SB ? g.nb - g.p2 - i0 : SB;
+            // column j (relative) of the band holds the rows max(j, i0) .. i0 + rows - 1
+            int j = 0;
+            for (;;) {
+                const int lo = j > i0 ? j : i0;
+                const int cnt = i0 + rows - lo;
+                if (t < cnt) { r = g.p2 + lo + t; break; }
+                t -= cnt;
+                ++j;
+            }
+            c = g.p2 + j;
+        }
         A0 = Ab + (size_t)r * TM * g.ldA + (size_t)g.p0 * TM; dA = TM;
         B0 = Bb + (size_t)c * TM * g.ldB + (size_t)g.p0 * TM; dB = TM;
         nkt = g.p1 - g.p0;
