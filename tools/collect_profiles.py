@@ -20,7 +20,7 @@ def summary(d):
 
 
 def per_kernel(d, counter):
-    cc = list(csv.DictReader(open(glob.glob(d + '/*/*counter_collection.csv')[0])))
+    cc = list(csv.DictReader(open(max(glob.glob(d + '/*/*counter_collection.csv'), key=os.path.getmtime))))
     out = {}
     for r in cc:
         if r['Counter_Name'] != counter:
@@ -47,7 +47,7 @@ def main():
         if not os.path.exists(os.path.join(src, a)):
             continue
         shutil.copy(os.path.join(src, a), os.path.join(dst, '%s_%s' % (pre, b)))
-    shutil.copy(glob.glob(src + '/stats/*/*kernel_stats.csv')[0], os.path.join(dst, pre + '_bench_kernel_stats.csv'))
+    shutil.copy(max(glob.glob(src + '/stats/*/*kernel_stats.csv'), key=os.path.getmtime), os.path.join(dst, pre + '_bench_kernel_stats.csv'))
     for d, name in (('pmc_fetch', 'pmc_fetch_size'), ('pmc_write', 'pmc_write_size'), ('pmc_valu', 'pmc_valu_cfg3'),
                     ('pmc_valu_cfg4', 'pmc_valu_cfg4'), ('pmc_mfma', 'pmc_mfma'), ('pmc_mfma_q1', 'pmc_mfma_q1')):
         if not os.path.isdir(os.path.join(src, d)):

@@ -1,8 +1,8 @@
 """Summarise a rocprofv3 --pmc ... --kernel-trace CSV directory: per kernel name, summed counters and durations."""
-import csv, collections, glob, sys
+import csv, collections, glob, os, sys
 d = sys.argv[1]
-cc = list(csv.DictReader(open(glob.glob(d + '/*/*counter_collection.csv')[0])))
-kt = {r['Dispatch_Id']: r for r in csv.DictReader(open(glob.glob(d + '/*/*kernel_trace.csv')[0]))}
+cc = list(csv.DictReader(open(max(glob.glob(d + '/*/*counter_collection.csv'), key=os.path.getmtime))))
+kt = {r['Dispatch_Id']: r for r in csv.DictReader(open(max(glob.glob(d + '/*/*kernel_trace.csv'), key=os.path.getmtime)))}
 agg = collections.defaultdict(lambda: collections.defaultdict(float))
 seen = set()
 for r in cc:
