@@ -92,6 +92,9 @@ typedef struct lcgp_sched {
     int progressive_lauum;  /* with the progressive inverse: A^-1 = W^T W is accumulated behind the chain as well when the matrix
                                has at most this many 64-blocks per side (48); beyond, only L^-1 is, and A^-1 takes the one
                                launch of lcgp_lauum after the factorisation (0 = always that) */
+    int pair_tiles;         /* two consecutive panels share ONE trailing update with K = 2 panels on the columns between the
+                               second panel and the far columns when that region holds at least this many 64x64 tiles (the
+                               first panel then only updates the second panel's own columns); 0 = never */
 } lcgp_sched;
 int lcgp_sched_default(lcgp_sched* sched /*host out*/);
 

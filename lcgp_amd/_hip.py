@@ -25,7 +25,7 @@ class Sched(C.Structure):
     """lcgp_sched of include/lcgp_hip.h: launch shapes of the factorisation / inverse, passed per call."""
     _fields_ = [("outer_blocks", C.c_int), ("syrk_small_tiles", C.c_int), ("trtri_small_tiles", C.c_int),
                 ("lauum_small_tiles", C.c_int), ("trtri_level_small", C.c_int), ("fill_leaf", C.c_int),
-                ("fill_step", C.c_int), ("leaf_in_wide", C.c_int), ("progressive_tiles", C.c_int), ("progressive_far", C.c_int), ("progressive_lauum", C.c_int)]
+                ("fill_step", C.c_int), ("leaf_in_wide", C.c_int), ("progressive_tiles", C.c_int), ("progressive_far", C.c_int), ("progressive_lauum", C.c_int), ("pair_tiles", C.c_int)]
 
 
 # every symbol include/lcgp_hip.h declares: name -> (restype, argtypes)

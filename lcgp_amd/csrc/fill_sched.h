@@ -275,6 +275,9 @@ struct PlanParams {
     bool far_rides;          // the far columns of a trailing update ride on the next panel's chain (else: one wide launch)
     bool with_dupd = true;   // progressive: A^-1 = W^T W is accumulated behind the chain too (else only L^-1 is; the caller
                              // then forms A^-1 in one launch after the factorisation)
+    int pair_tiles = 0;      // > 0: two consecutive panels share ONE trailing update with K = 2 ob on the columns between the second
+                             // panel and the far columns when that region has at least this many 64x64 tiles x components (the
+                             // first panel only updates the second panel's own columns); 0 = every panel updates everything
 };
 
 enum LaunchKind {
@@ -346,17 +349,36 @@ class Planner {
                     }
                 }
             }
+            // Paired panels: the update of the columns [mid, cf) by THIS panel waits for the next one and runs with K = 2 ob --
+            // half the read-modify-write passes over that region, twice the K loop per tile (measured 6-9 % faster on it:
+            // profiles/r06_deferred_k512_microbench.txt).  The far columns keep riding on the chain launches panel by panel.
+            int k_lo = J;                                      // first block column of the K range of this panel's wide update
+            int c_hi = cf;
+            if (pair_J >= 0) {                                 // second panel of a pair
+                cf = pair_cf;
+                next_leaf = false;                             // (the diagonal block (pe, pe) still lacks the first panel)
+                k_lo = pair_J;
+                c_hi = cf;
+                pair_J = -1;
+            } else if (pp.pair_tiles > 0 && !pp.progressive && !next_leaf && pe - J == ob && mid - pe == ob && mid + ob + 2 <= cf &&
+                       (long long)q * trapezoid_tiles(nb, mid, cf) >= pp.pair_tiles) {
+                pair_J = J;
+                pair_cf = cf;
+                next_leaf = false;
+                c_hi = mid;                                    // only the next panel's own columns now
+            }
             panel(J, pe, leaf_done, next_leaf);
             if (pe >= nb) break;
-            if (pe < cf) {
+            if (pe < c_hi) {
                 Launch l;
-                l.kind = L_TRAIL; l.J = J; l.pe = pe; l.c_lo = pe; l.c_hi = cf; l.tiles128 = wide128(cf) ? 1 : 0;
+                l.kind = L_TRAIL; l.J = k_lo; l.pe = pe; l.c_lo = pe; l.c_hi = c_hi;
+                l.tiles128 = t128 && (long long)q * trapezoid_tiles(nb / 2, pe / 2, c_hi / 2) >= pp.syrk_small_tiles ? 1 : 0;
                 l.with_leaf = next_leaf ? 1 : 0;
                 l.fs.njobs = 0; l.fs.nblk = 0;
                 launches.push_back(l);
                 fq.end_launch();
             }
-            leaf_done = next_leaf && pe < cf;
+            leaf_done = next_leaf && pe < c_hi;
             queue_far_update(J, pe, cf);
         }
         // the tail of the progressive inverse: what the chain launches did not carry, in as few dependent launches as
@@ -374,6 +396,7 @@ class Planner {
     bool failed = false;
 
  private:
+    int pair_J = -1, pair_cf = 0;       // first panel of an open pair and the far boundary the two share
     PlanParams pp;
     FillQueue fq;
     int urgent_row = 0;           // CUPD rows below this 128-row block feed the next row of the inverse

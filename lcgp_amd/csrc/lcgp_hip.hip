@@ -23,7 +23,7 @@
 #include "../../include/lcgp_hip.h"
 #include "fill_sched.h"
 
-#define LCGP_VERSION 500
+#define LCGP_VERSION 510
 
 namespace {
 
@@ -713,6 +713,9 @@ __global__ __launch_bounds__(256, 2) void leaf_kernel(T* __restrict__ M, T* __re
 //   MK : element (m, k) at P[m * ld + k]      KM : element (m, k) at P[k * ld + m]
 // and staged in LDS as [k][m] (KT = 16 k rows per stage, double buffered through registers).
 // ---------------------------------------------------------------------------------------------------
+#ifndef LCGP_PAIR_TILES_DEFAULT
+#define LCGP_PAIR_TILES_DEFAULT 4000
+#endif
 #ifndef LCGP_EXP
 #define LCGP_EXP 0      // destructive timing experiments (tools/build_variant.sh ... -DLCGP_EXP=n); 0 in every product build
 #endif
@@ -2530,13 +2533,15 @@ inline lcgp_sched default_sched() {
     s.progressive_lauum = 48;      // ... and A^-1 = W^T W accumulated behind the chain as well up to this many 64-blocks per side
                                    // (n = 2048: 1.12 -> 0.98 ms; at n = 4096 its tail is one ragged launch of long K loops
                                    // that loses to the one-launch W^T W: 2.54 vs 2.43 ms)
+    s.pair_tiles = LCGP_PAIR_TILES_DEFAULT;   // paired panels: one K = 2 ob update of the columns between the second panel and the far ones
     return s;
 }
 
 inline int check_sched(const lcgp_sched& s) {
     if (s.outer_blocks < 0 || s.outer_blocks > 64) return bad("sched.outer_blocks must be in [0, 64]");
     if (s.syrk_small_tiles < 0 || s.trtri_small_tiles < 0 || s.lauum_small_tiles < 0 || s.trtri_level_small < 0 ||
-        s.fill_leaf < 0 || s.fill_step < 0 || s.leaf_in_wide < 0 || s.progressive_tiles < 0 || s.progressive_lauum < 0)
+        s.fill_leaf < 0 || s.fill_step < 0 || s.leaf_in_wide < 0 || s.progressive_tiles < 0 || s.progressive_lauum < 0 ||
+        s.pair_tiles < 0)
         return bad("sched fields must be >= 0");
     return 0;
 }
@@ -2621,6 +2626,7 @@ inline lcgp_fill::PlanParams plan_params(int dtype, int nb, int q, bool with_inv
     pp.progressive = prog;
     pp.far_rides = !(pp.progressive && sc.progressive_far == 0);
     pp.with_dupd = nb <= sc.progressive_lauum;
+    pp.pair_tiles = sc.pair_tiles;
     if (inverse_done) *inverse_done = pp.progressive ? (pp.with_dupd ? 2 : 1) : 0;
     return pp;
 }

@@ -1,6 +1,6 @@
 // Prints the launch plan of one factorisation (lcgp_amd/csrc/fill_sched.h: Planner) as text, for the CPU replay in
 // tests/test_fill_sched.py.  Host-only: g++ -std=c++17 -I lcgp_amd/csrc tests/native/dump_plan.cpp
-//   usage: dump_plan nb q ob syrk_small_tiles fill_leaf fill_step leaf_in_wide progressive [far_rides [with_dupd]]
+//   usage: dump_plan nb q ob syrk_small_tiles fill_leaf fill_step leaf_in_wide progressive [far_rides [with_dupd [pair_tiles]]]
 // One line per launch ("L key=value ..."), followed by its filler jobs ("J ...").
 #include <cstdio>
 #include <cstdlib>
@@ -12,13 +12,14 @@ static void print_job(const lcgp_fill::FillJob& j) {
 }
 
 int main(int argc, char** argv) {
-    if (argc < 9 || argc > 11) { fprintf(stderr, "usage: dump_plan nb q ob syrk_small fill_leaf fill_step leaf_in_wide progressive\n"); return 2; }
+    if (argc < 9 || argc > 12) { fprintf(stderr, "usage: dump_plan nb q ob syrk_small fill_leaf fill_step leaf_in_wide progressive\n"); return 2; }
     lcgp_fill::PlanParams pp;
     pp.nb = atoi(argv[1]); pp.q = atoi(argv[2]); pp.ob = atoi(argv[3]); pp.syrk_small_tiles = atoi(argv[4]);
     pp.fill_leaf = atoi(argv[5]); pp.fill_step = atoi(argv[6]); pp.leaf_in_wide = atoi(argv[7]);
     pp.progressive = atoi(argv[8]) != 0;
     pp.far_rides = argc > 9 ? atoi(argv[9]) != 0 : true;
     pp.with_dupd = argc > 10 ? atoi(argv[10]) != 0 : true;
+    pp.pair_tiles = argc > 11 ? atoi(argv[11]) : 0;
     lcgp_fill::Planner plan(pp);
     plan.run();
     if (plan.failed) { printf("FAILED\n"); return 1; }

@@ -23,9 +23,10 @@ def dump_plan(tmp_path_factory):
     subprocess.run(['g++', '-std=c++17', '-O1', '-I', os.path.join(ROOT, 'lcgp_amd', 'csrc'), '-o', exe,
                     os.path.join(ROOT, 'tests', 'native', 'dump_plan.cpp')], check=True)
 
-    def run(nb, q, ob, syrk_small=3000, fill_leaf=248, fill_step=248, leaf_in_wide=2048, progressive=1, far_rides=1, with_dupd=1):
+    def run(nb, q, ob, syrk_small=3000, fill_leaf=248, fill_step=248, leaf_in_wide=2048, progressive=1, far_rides=1, with_dupd=1,
+            pair_tiles=0):
         out = subprocess.run([exe] + [str(v) for v in (nb, q, ob, syrk_small, fill_leaf, fill_step, leaf_in_wide, progressive,
-                                                       far_rides, with_dupd)],
+                                                       far_rides, with_dupd, pair_tiles)],
                              check=True, capture_output=True, text=True).stdout
         assert 'FAILED' not in out
         launches = []
@@ -287,6 +288,27 @@ def test_plan_without_inverse_replays_to_the_factor(dump_plan, nb, q, ob, kw):
     launches = dump_plan(nb, q, ob, progressive=0, **kw)
     assert all(jb['type'] == 1 for l in launches for jb in l['jobs'])       # only trailing-update filler
     r = Replay(nb, q, seed=nb)
+    r.run(launches)
+    r.check(inverse=False)
+
+
+@pytest.mark.parametrize('nb,q,ob,kw', [(64, 8, 4, dict(pair_tiles=4000)), (64, 8, 4, dict(pair_tiles=1)), (32, 6, 4, dict(pair_tiles=1)),
+                                        (18, 1, 4, dict(pair_tiles=1)), (10, 3, 4, dict(pair_tiles=1)), (24, 2, 8, dict(pair_tiles=1)),
+                                        (32, 2, 4, dict(pair_tiles=1, far_rides=0)), (32, 1, 4, dict(pair_tiles=1, fill_leaf=40, fill_step=24)),
+                                        (40, 2, 2, dict(pair_tiles=1, leaf_in_wide=0)), (24, 4, 4, dict(pair_tiles=1, leaf_in_wide=0, fill_leaf=8, fill_step=8)),
+                                        (24, 4, 4, dict(pair_tiles=1, leaf_in_wide=0, fill_leaf=8, fill_step=8, syrk_small=16)),
+                                        (26, 1, 4, dict(pair_tiles=1, leaf_in_wide=0, fill_leaf=0, fill_step=0)), (22, 3, 6, dict(pair_tiles=1, leaf_in_wide=0, fill_leaf=6, fill_step=6))])
+def test_plan_with_paired_panels_replays_to_the_factor(dump_plan, nb, q, ob, kw):
+    """two consecutive panels share one trailing update with K = 2 ob on the columns between the second panel and the far
+    columns (PlanParams::pair_tiles): same factor, every hazard check of the replay"""
+    launches = dump_plan(nb, q, ob, progressive=0, **kw)
+    wide = [l for l in launches if l['kind'] == 3]
+    if nb == 64 or (kw.get('leaf_in_wide') == 0 and ob < 6):
+        assert any(l['pe'] - l['J'] == 2 * ob for l in wide), 'no paired update in this plan'
+    for l in wide:
+        assert l['pe'] - l['J'] in (ob, 2 * ob) or l['pe'] == nb
+        assert not (l['pe'] - l['J'] == 2 * ob and l['with_leaf'])      # the diagonal block would lack the first panel
+    r = Replay(nb, q, seed=5 * nb + q)
     r.run(launches)
     r.check(inverse=False)
 

@@ -220,6 +220,9 @@ def test_schedule_parameters_do_not_change_results():
                        dict(leaf_in_wide=100000), dict(leaf_in_wide=100000, outer_blocks=2), dict(trtri_level_small=0),
                        dict(trtri_level_small=100000, trtri_small_tiles=0), dict(lauum_small_tiles=0),
                        dict(lauum_small_tiles=100000, trtri_small_tiles=100000),
+                       # paired panels (one K = 2-panel update of the middle columns): off, and forced at this size
+                       dict(pair_tiles=0), dict(pair_tiles=1, progressive_tiles=0), dict(pair_tiles=1, progressive_tiles=0, leaf_in_wide=0),
+                       dict(pair_tiles=1, progressive_tiles=0, leaf_in_wide=0, outer_blocks=2, fill_leaf=4, fill_step=4),
                        # the inverse formed behind the chain (fill_sched.h) and after it
                        dict(progressive_tiles=0), dict(progressive_tiles=1 << 30), dict(progressive_tiles=1 << 30, outer_blocks=2),
                        dict(progressive_tiles=1 << 30, outer_blocks=8), dict(progressive_tiles=1 << 30, fill_leaf=0, fill_step=0),
@@ -248,6 +251,10 @@ def test_wide_tile_schedules_agree_at_medium_size():
                        dict(syrk_small_tiles=16, leaf_in_wide=100000), dict(syrk_small_tiles=16, fill_leaf=40, fill_step=56),
                        dict(syrk_small_tiles=16, outer_blocks=2), dict(syrk_small_tiles=16, outer_blocks=8),
                        dict(syrk_small_tiles=200, leaf_in_wide=300), dict(syrk_small_tiles=1, fill_leaf=8, fill_step=8),
+                       dict(pair_tiles=1, progressive_tiles=0, leaf_in_wide=0), dict(pair_tiles=1, progressive_tiles=0, leaf_in_wide=0, syrk_small_tiles=16),
+                       dict(pair_tiles=1, progressive_tiles=0, leaf_in_wide=0, fill_leaf=8, fill_step=8, outer_blocks=2), dict(pair_tiles=0),
+                       dict(pair_tiles=1, progressive_tiles=0, leaf_in_wide=0, fill_leaf=8, fill_step=8),
+                       dict(pair_tiles=1, progressive_tiles=0, leaf_in_wide=0, fill_leaf=8, fill_step=8, syrk_small_tiles=16),
                        dict(progressive_tiles=0), dict(progressive_tiles=1 << 30), dict(progressive_tiles=1 << 30, syrk_small_tiles=16),
                        dict(progressive_tiles=1 << 30, progressive_far=0, syrk_small_tiles=16),
                        dict(progressive_tiles=1 << 30, fill_leaf=40, fill_step=56), dict(progressive_tiles=1 << 30, outer_blocks=8)):
